@@ -1,0 +1,245 @@
+"""ctypes binding of libsw_hip.so, shaped like the reference's cgo bridge.
+
+Mirrors internal/worker/worker_rust_bridge.go (FindRustAlignmentSimdLowMem :105-124, FindRustAlignmentSimd
+:84-103, FindRustAlignmentSequential :63-82, GoResult :20-26) and findAlignmentWithFallback
+(internal/worker/worker_impl.go:170-202) so that the parity tests read like calls from the Go worker.
+Go is not available in the build image; INTEGRATION.md shows the two cgo lines a maintainer changes.
+
+Nothing here computes an alignment: if the library or a GPU is missing the calls raise SwHipError.
+"""
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libsw_hip.so")
+
+
+class SwHipError(RuntimeError):
+    pass
+
+
+class CResult(C.Structure):  # include/sw.h struct Result == rust/header/sw.h:4-11
+    _fields_ = [("query_ptr", C.c_void_p), ("target_ptr", C.c_void_p), ("score", C.c_uint16),
+                ("max_x", C.c_uint64), ("max_y", C.c_uint64)]
+
+
+class CScores(C.Structure):  # include/sw.h struct AlignmentScores == rust/header/sw.h:13-18
+    _fields_ = [("gap", C.c_uint16), ("match", C.c_uint16), ("miss", C.c_uint16)]
+
+
+class CHit(C.Structure):  # include/sw_hip.h struct sw_hit
+    _fields_ = [("target_index", C.c_uint64), ("score", C.c_int32), ("length", C.c_uint32),
+                ("max_x", C.c_uint64), ("max_y", C.c_uint64), ("query_aln", C.c_void_p),
+                ("target_aln", C.c_void_p)]
+
+
+class CStats(C.Structure):  # include/sw_hip.h struct sw_kernel_stats
+    _fields_ = [("score_kernel_ms", C.c_double), ("exact_kernel_ms", C.c_double), ("score_cells", C.c_uint64),
+                ("exact_cells", C.c_uint64), ("score_launches", C.c_uint32), ("rerun_pairs", C.c_uint32)]
+
+
+@dataclass
+class AlignmentScore:
+    """internal/smithwaterman/smithwaterman.go:13-17; the worker passes penalties NEGATED
+    (worker_impl.go:126-127), i.e. mismatch_penalty and gap_penalty are negative numbers here."""
+    match_score: int
+    mismatch_penalty: int
+    gap_penalty: int
+
+    def c(self):
+        return CScores(self.gap_penalty & 0xFFFF, self.match_score & 0xFFFF, self.mismatch_penalty & 0xFFFF)
+
+
+@dataclass
+class GoResult:  # worker_rust_bridge.go:20-26
+    query: str
+    target: str
+    score: int   # uint16
+    max_x: int   # uint64
+    max_y: int   # uint64
+    score32: int = 0
+
+
+_lib = None
+
+
+def lib():
+    """Loads libsw_hip.so and declares every symbol of include/sw.h and include/sw_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise SwHipError(f"{path} is missing: build it with `python -m dlsa_amd.build` (there is no CPU fallback)")
+    L = C.CDLL(path)
+    RP = C.POINTER(CResult)
+    for name in ("find_alignment_low_memory", "find_alignment_simd", "find_alignment_sequential_straight",
+                 "find_alignment_sequential"):
+        f = getattr(L, name)
+        f.argtypes = [C.c_char_p, C.c_char_p, CScores]
+        f.restype = RP
+    L.find_alignment_parallel.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t, CScores]
+    L.find_alignment_parallel.restype = RP
+    L.free_alignment_result.argtypes = [RP]
+    L.free_alignment_result.restype = None
+    L.free_c_string.argtypes = [C.c_void_p]
+    L.free_c_string.restype = None
+    L.sw_hip_init.argtypes = [C.c_int]
+    L.sw_hip_init.restype = C.c_int
+    L.sw_hip_last_error.restype = C.c_char_p
+    L.sw_hip_version.restype = C.c_char_p
+    L.sw_result_score32.argtypes = [RP]
+    L.sw_result_score32.restype = C.c_int32
+    L.sw_align_batch.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_size_t, CScores, C.c_int,
+                                 C.POINTER(RP)]
+    L.sw_align_batch.restype = C.c_int
+    L.sw_db_create.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64]
+    L.sw_db_create.restype = C.c_void_p
+    L.sw_db_load_fasta.argtypes = [C.c_char_p]
+    L.sw_db_load_fasta.restype = C.c_void_p
+    L.sw_db_free.argtypes = [C.c_void_p]
+    L.sw_db_free.restype = None
+    L.sw_db_size.argtypes = [C.c_void_p]
+    L.sw_db_size.restype = C.c_uint64
+    L.sw_db_residues.argtypes = [C.c_void_p]
+    L.sw_db_residues.restype = C.c_uint64
+    L.sw_db_search_topk.argtypes = [C.c_void_p, C.c_char_p, CScores, C.c_int, C.POINTER(CHit), C.POINTER(C.c_int)]
+    L.sw_db_search_topk.restype = C.c_int
+    L.sw_db_scores.argtypes = [C.c_void_p, C.c_char_p, CScores, C.POINTER(C.c_int32)]
+    L.sw_db_scores.restype = C.c_int
+    L.sw_hits_free.argtypes = [C.POINTER(CHit), C.c_int]
+    L.sw_hits_free.restype = None
+    L.sw_hip_last_stats.argtypes = [C.POINTER(CStats)]
+    L.sw_hip_last_stats.restype = C.c_int
+    L.sw_hip_benchmark_cups.restype = C.c_float
+    _lib = L
+    return L
+
+
+def last_error():
+    return lib().sw_hip_last_error().decode("utf-8", "replace")
+
+
+def _b(s):
+    return s if isinstance(s, bytes) else s.encode("utf-8")
+
+
+def _convert(L, res):
+    """convertResultToGoResult (worker_rust_bridge.go:131-139) + FreeAlignmentResult (:142-144)."""
+    r = res.contents
+    out = GoResult(C.string_at(r.query_ptr).decode("utf-8"), C.string_at(r.target_ptr).decode("utf-8"),
+                   int(r.score), int(r.max_x), int(r.max_y), int(L.sw_result_score32(res)))
+    L.free_alignment_result(res)
+    return out
+
+
+def _call(name, msg, query, target, score):
+    L = lib()
+    res = getattr(L, name)(_b(query), _b(target), score.c())
+    if not res:
+        return None, SwHipError(f"{msg}: {last_error()}")
+    return _convert(L, res), None
+
+
+def find_rust_alignment_simd_low_mem(query, target, score):
+    return _call("find_alignment_low_memory", "Crash in SIMD ringbuffer alignment", query, target, score)
+
+
+def find_rust_alignment_simd(query, target, score):
+    return _call("find_alignment_simd", "Crash in rust SIMD alignment", query, target, score)
+
+
+def find_rust_alignment_sequential(query, target, score):
+    return _call("find_alignment_sequential_straight", "Crash in rust sequential alignment", query, target, score)
+
+
+def find_alignment_with_fallback(query, target, score):
+    """internal/worker/worker_impl.go:170-202: low memory, then simd, then sequential."""
+    for f in (find_rust_alignment_simd_low_mem, find_rust_alignment_simd, find_rust_alignment_sequential):
+        res, err = f(query, target, score)
+        if err is None:
+            return res, None
+    return None, SwHipError("All alignment functions failed to align a sequence")
+
+
+def align_batch(queries, targets, score, path=0):
+    """sw_align_batch: one GPU submission for a list of pairs; returns a list of GoResult/None."""
+    L = lib()
+    n = len(queries)
+    qs = (C.c_char_p * n)(*[_b(q) for q in queries])
+    ts = (C.c_char_p * n)(*[_b(t) for t in targets])
+    out = (C.POINTER(CResult) * n)()
+    rc = L.sw_align_batch(qs, ts, n, score.c(), path, out)
+    if rc != 0:
+        raise SwHipError(f"sw_align_batch failed ({rc}): {last_error()}")
+    return [(_convert(L, out[i]) if out[i] else None) for i in range(n)]
+
+
+class Database:
+    """A resident target database (sw_db_*)."""
+
+    def __init__(self, seqs=None, flat=None, offsets=None):
+        L = lib()
+        if seqs is not None:
+            bs = [_b(s) for s in seqs]
+            flat = b"".join(bs)
+            offs = [0]
+            for s in bs:
+                offs.append(offs[-1] + len(s))
+            n = len(bs)
+            off_arr = (C.c_uint64 * (n + 1))(*offs)
+            self._h = L.sw_db_create(flat, off_arr, n)
+        else:
+            import numpy as np
+            offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+            n = len(offsets) - 1
+            buf = flat if isinstance(flat, bytes) else flat.tobytes()
+            self._h = L.sw_db_create(buf, offsets.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+        if not self._h:
+            raise SwHipError(f"sw_db_create failed: {last_error()}")
+        self.n = n
+
+    def close(self):
+        if self._h:
+            lib().sw_db_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def scores(self, query, score):
+        import numpy as np
+        out = np.zeros(self.n, dtype=np.int32)
+        rc = lib().sw_db_scores(self._h, _b(query), score.c(), out.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc != 0:
+            raise SwHipError(f"sw_db_scores failed ({rc}): {last_error()}")
+        return out
+
+    def search_topk(self, query, score, k):
+        L = lib()
+        hits = (CHit * max(k, 1))()
+        nh = C.c_int(0)
+        rc = L.sw_db_search_topk(self._h, _b(query), score.c(), k, hits, C.byref(nh))
+        if rc != 0:
+            raise SwHipError(f"sw_db_search_topk failed ({rc}): {last_error()}")
+        out = []
+        for i in range(nh.value):
+            h = hits[i]
+            out.append(dict(target_index=int(h.target_index), score=int(h.score), length=int(h.length),
+                            max_x=int(h.max_x), max_y=int(h.max_y),
+                            query_aln=C.string_at(h.query_aln).decode(), target_aln=C.string_at(h.target_aln).decode()))
+        L.sw_hits_free(hits, nh.value)
+        return out
+
+
+def last_stats():
+    st = CStats()
+    lib().sw_hip_last_stats(C.byref(st))
+    return {k: getattr(st, k) for k, _ in CStats._fields_}

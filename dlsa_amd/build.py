@@ -1,0 +1,43 @@
+"""Builds dlsa_amd/lib/libsw_hip.so (HIP kernels + C ABI) for gfx950 with hipcc.
+
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container; the .so is kept
+in-tree (git-ignored) so that it travels to the GPU box with the source snapshot.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libsw_hip.so")
+SOURCES = ["sw_exact.hip", "sw_score.hip", "sw_lib.cpp"]
+HEADERS = [os.path.join(CSRC, "sw_internal.h"), os.path.join(HERE, "..", "include", "sw.h"),
+           os.path.join(HERE, "..", "include", "sw_hip.h")]
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    m = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > m for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB,
+           os.path.join(CSRC, "sw_exact.hip"), os.path.join(CSRC, "sw_score.hip"),
+           "-x", "hip", os.path.join(CSRC, "sw_lib.cpp")]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -1,0 +1,85 @@
+// dlsa_amd/csrc/sw_internal.h -- shared between the translation units of libsw_hip.so.
+// Not installed; the public contract is include/sw.h + include/sw_hip.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+namespace swhip {
+
+// ---- scoring ------------------------------------------------------------------------------------------
+struct Scoring {
+  int match, miss, gap;  // as the reference sees them: match > 0, miss < 0, gap < 0 on the fast paths
+};
+
+// ---- exact (intra-task) kernel ------------------------------------------------------------------------
+// Which reference entry point a pair reproduces decides four small integers (DESIGN.md "Effective
+// semantics"); the kernel itself is one plain linear-gap SW over the cells
+//   { (x, j) : 1 <= x <= Q, 1 <= j <= (x == 1 ? T0 : Tlim) }.
+struct ExactPair {
+  const uint16_t* q;  // query symbols (Unicode scalar truncated to u16, as rust/src/algorithm/mod.rs:78,224)
+  const uint16_t* t;  // target symbols
+  uint32_t Q, T;      // real lengths
+  uint32_t Tlim;      // last column computed for rows x >= 2
+  uint32_t T0;        // last column computed for row x == 1
+  uint32_t phaseQp;   // != 0: ring path with T < Qp, two-phase discovery order, value = Qp
+  uint32_t straight;  // != 0: tie order of find_alignment_sequential_straight (smallest j, then x)
+  int32_t* bnd;       // scratch: 2 * bnd_pitch ints (H of the last row of the previous strip)
+  uint32_t bnd_pitch;
+  uint32_t* dirs;     // nullptr: score + best cell only.  Else 2 bits per cell (layout in sw_exact.hip)
+  uint32_t nkb;       // 16-step blocks per strip
+  uint8_t* ops;       // traceback ops written by the walker (capacity Q + T)
+};
+struct ExactOut {
+  int32_t score;  // H of the best cell (0: no hit)
+  uint32_t bx;    // best cell, 1-based query index (0: none)
+  uint32_t bj;    // best cell, 1-based target index
+  uint32_t nops;  // number of traceback ops (walker)
+};
+constexpr int kExactRPL = 4;             // rows per lane
+constexpr int kExactSH = 64 * kExactRPL; // rows per strip
+
+// steps per strip (multiple of 64) for a pair whose widest row has `maxcol` columns
+inline uint32_t exact_nsteps(uint32_t maxcol) { return maxcol == 0 ? 0 : ((maxcol + 63 + 63) / 64) * 64; }
+inline uint32_t exact_nstrips(uint32_t Q) { return (Q + kExactSH - 1) / kExactSH; }
+inline size_t exact_dir_words(uint32_t Q, uint32_t maxcol) {
+  return (size_t)exact_nstrips(Q) * (exact_nsteps(maxcol) / 16) * kExactRPL * 64;
+}
+
+hipError_t launch_exact(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, Scoring sc,
+                        hipStream_t stream);
+hipError_t launch_walk(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, Scoring sc,
+                       hipStream_t stream);
+
+// ---- inter-task score kernel ---------------------------------------------------------------------------
+constexpr int kScoreR = 16;       // target columns per wave (one 2-bit packed dword per target)
+constexpr int kScoreB = 16;       // query rows per pipeline block (one 2-bit packed dword of the query)
+constexpr int kGroupTargets = 128; // 64 lanes x 2 packed int16 halves
+
+struct ScoreGroup {       // one group of up to 128 length-sorted targets
+  uint64_t word_off;      // offset (in dwords) of this group's packed residues: [strip][half][lane]
+  uint32_t nstrips;       // ceil(max length / 16)
+  uint32_t first_slot;    // index of lane 0 / half 0 in the per-slot arrays (lens, order); 128 slots
+};
+
+struct ScoreParams {
+  const uint32_t* words;      // packed residues, 2 bits each, 16 per dword
+  const ScoreGroup* groups;   // n_groups
+  const uint32_t* lens;       // per slot: target length (0 for padding slots)
+  const uint32_t* qwords;     // query, 2 bits per residue, 16 per dword (row-block aligned)
+  uint32_t Q;
+  uint32_t n_groups;
+  int32_t* slot_scores;       // per slot: best H over the effective domain (32767 = saturated)
+  uint32_t* gbound;           // per resident workgroup: 2 * Q_pad * 64 dwords of inter-pass boundary
+  uint64_t gbound_stride;     // dwords per workgroup
+  uint32_t* ticket;           // work counter (zeroed before launch)
+  int match, miss, gap;
+};
+hipError_t launch_score(const ScoreParams& p, int n_workgroups, hipStream_t stream);
+int score_waves_per_group();
+
+}  // namespace swhip

@@ -1,0 +1,967 @@
+// dlsa_amd/csrc/sw_lib.cpp -- host side of libsw_hip.so: the C ABI of include/sw.h and
+// include/sw_hip.h over the HIP kernels in sw_exact.hip / sw_score.hip.
+//
+// Mirrors, on the callee side of the cgo boundary, what rust/src/bindings.rs does around the
+// algorithm: C string -> UTF-8 check -> symbols (bindings.rs:122-129), run, box a Result with two
+// heap strings (bindings.rs:143-151), NULL on any failure (bindings.rs:153-156).  There is no CPU
+// implementation of the alignment in this file: every cell is computed by a HIP kernel and a missing
+// GPU makes every entry point fail loudly (NULL / SW_E_NOGPU + sw_hip_last_error()).
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/sw_hip.h"
+#include "sw_internal.h"
+
+using namespace swhip;
+
+namespace {
+
+// ---- errors --------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIPCK(expr)                                                                                  \
+  do {                                                                                               \
+    hipError_t e__ = (expr);                                                                         \
+    if (e__ != hipSuccess)                                                                           \
+      return fail(SW_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                     \
+  } while (0)
+
+// ---- device context --------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return SW_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 8 + 4096;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      e = hipMalloc(&p, bytes);
+      want = bytes;
+    }
+    if (e != hipSuccess) return fail(SW_E_NOMEM, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    cap = want;
+    return SW_OK;
+  }
+};
+
+struct Context {
+  std::mutex mu;  // one GPU submission at a time; the ABI is entered from many threads
+  bool ready = false;
+  int device = 0;
+  int cus = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  DevBuf sym, pairs, outs, dirs, bnd, ops;            // exact path scratch
+  DevBuf qwords, slot_scores, gbound, ticket;          // score path scratch
+  sw_kernel_stats stats{};
+  size_t scratch_budget = (size_t)8 << 30;
+};
+Context g_ctx;
+
+int ctx_init_locked(int device) {
+  Context& c = g_ctx;
+  if (c.ready) {
+    if (device >= 0 && device != c.device) return fail(SW_E_ARG, "sw_hip_init: already initialised on another device");
+    return SW_OK;
+  }
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return fail(SW_E_NOGPU, std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "count 0") +
+                                "); libsw_hip has no CPU fallback");
+  if (device < 0) device = 0;
+  if (device >= n) return fail(SW_E_ARG, "sw_hip_init: device index out of range");
+  HIPCK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCK(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    return fail(SW_E_NOGPU, std::string("device is ") + prop.gcnArchName + ", the kernels are built for gfx950 only");
+  c.cus = prop.multiProcessorCount;
+  HIPCK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  HIPCK(hipEventCreate(&c.ev0));
+  HIPCK(hipEventCreate(&c.ev1));
+  HIPCK(hipEventCreate(&c.ev2));
+  HIPCK(hipEventCreate(&c.ev3));
+  if (const char* mb = getenv("SW_HIP_SCRATCH_MB")) c.scratch_budget = (size_t)atoll(mb) << 20;
+  c.device = device;
+  c.ready = true;
+  return SW_OK;
+}
+
+// ---- UTF-8 -> symbols --------------------------------------------------------------------------------------
+// rust/src/bindings.rs:125-129: String::from_utf8(...).unwrap().chars().collect(); invalid UTF-8 panics
+// -> NULL.  cps receives the Unicode scalar values (for re-encoding the alignment), sym their u16
+// truncation (`*x as u16`, rust/src/algorithm/mod.rs:78,224) which is what scores are computed on.
+bool decode_utf8(const char* s, std::vector<uint32_t>& cps) {
+  const unsigned char* p = (const unsigned char*)s;
+  cps.clear();
+  while (*p) {
+    uint32_t c = *p;
+    if (c < 0x80) {
+      cps.push_back(c);
+      p++;
+      continue;
+    }
+    int n;
+    uint32_t minv;
+    if ((c & 0xE0) == 0xC0) { n = 1; c &= 0x1F; minv = 0x80; }
+    else if ((c & 0xF0) == 0xE0) { n = 2; c &= 0x0F; minv = 0x800; }
+    else if ((c & 0xF8) == 0xF0) { n = 3; c &= 0x07; minv = 0x10000; }
+    else return false;
+    for (int i = 1; i <= n; i++) {
+      if ((p[i] & 0xC0) != 0x80) return false;
+      c = (c << 6) | (p[i] & 0x3F);
+    }
+    if (c < minv || c > 0x10FFFF || (c >= 0xD800 && c <= 0xDFFF)) return false;
+    cps.push_back(c);
+    p += n + 1;
+  }
+  return true;
+}
+void encode_utf8(uint32_t c, std::string& out) {
+  if (c < 0x80) out.push_back((char)c);
+  else if (c < 0x800) { out.push_back((char)(0xC0 | (c >> 6))); out.push_back((char)(0x80 | (c & 0x3F))); }
+  else if (c < 0x10000) { out.push_back((char)(0xE0 | (c >> 12))); out.push_back((char)(0x80 | ((c >> 6) & 0x3F))); out.push_back((char)(0x80 | (c & 0x3F))); }
+  else { out.push_back((char)(0xF0 | (c >> 18))); out.push_back((char)(0x80 | ((c >> 12) & 0x3F))); out.push_back((char)(0x80 | ((c >> 6) & 0x3F))); out.push_back((char)(0x80 | (c & 0x3F))); }
+}
+
+inline uint32_t roundup64(uint32_t v) { return (v + 63u) / 64u * 64u; }
+
+// ---- the four integers that make one plain SW reproduce a reference entry point ---------------------------
+// DESIGN.md "Effective semantics"; proven equal to the restatement by tests/test_oracle_clean.py.
+struct PathParams {
+  uint32_t Tlim, T0, phaseQp, straight;
+};
+PathParams resolve_path(int path, uint32_t Q, uint32_t T) {
+  PathParams pp{T, T, 0, 0};
+  if (path == SW_PATH_STRAIGHT) {
+    pp.straight = 1;
+    return pp;
+  }
+  const uint32_t Qp = roundup64(Q), Tp = roundup64(T);
+  const bool full = (path == SW_PATH_SIMD) || ((uint64_t)T < 2ull * Q);  // rust/src/algorithm/mod.rs:213
+  if (full) {
+    if (T > 0 && T % 64 == 0) {        // algorithm/mod.rs:98,178: column Tp is skipped ...
+      pp.Tlim = T - 1;
+      pp.T0 = (Tp >= Qp) ? T : T - 1;  // ... except H(1,T) in the lane phase, algorithm/mod.rs:134
+    }
+  } else if (T < Qp) {                 // algorithm/mod.rs:251 with an empty lane phase (:313)
+    pp.T0 = T - 1;
+    pp.phaseQp = Qp;
+  }
+  return pp;
+}
+
+// ---- exact path driver ------------------------------------------------------------------------------------
+struct PairSpec {
+  const uint16_t* q;
+  uint32_t Q;
+  const uint16_t* t;
+  uint32_t T;
+  int path;
+};
+struct PairOut {
+  int32_t score = 0;
+  uint32_t bx = 0, bj = 0;
+  std::vector<uint8_t> ops;  // last alignment column first
+};
+
+// Runs pairs [begin, end) in one submission.  Caller holds the context mutex.
+int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc, bool want_trace, PairOut* outs) {
+  Context& c = g_ctx;
+  const size_t n = end - begin;
+  if (n == 0) return SW_OK;
+  // symbol pool, deduplicated by host pointer (a database search shares one query)
+  std::unordered_map<const uint16_t*, size_t> seen;
+  std::vector<uint16_t> pool;
+  auto add_seq = [&](const uint16_t* p, uint32_t len) -> size_t {
+    auto it = seen.find(p);
+    if (it != seen.end()) return it->second;
+    size_t off = pool.size();
+    pool.insert(pool.end(), p, p + len);
+    if (pool.size() & 1) pool.push_back(0);
+    seen.emplace(p, off);
+    return off;
+  };
+  std::vector<ExactPair> hp(n);
+  std::vector<size_t> qoff(n), toff(n);
+  size_t dir_words = 0, bnd_ints = 0, ops_bytes = 0;
+  for (size_t i = 0; i < n; i++) {
+    const PairSpec& s = specs[begin + i];
+    qoff[i] = add_seq(s.q, s.Q);
+    toff[i] = add_seq(s.t, s.T);
+    PathParams pp = resolve_path(s.path, s.Q, s.T);
+    ExactPair& e = hp[i];
+    e.Q = s.Q;
+    e.T = s.T;
+    e.Tlim = pp.Tlim;
+    e.T0 = pp.T0;
+    e.phaseQp = pp.phaseQp;
+    e.straight = pp.straight;
+    const uint32_t maxcol = std::max(pp.Tlim, pp.T0);
+    e.bnd_pitch = maxcol + 2;
+    e.nkb = exact_nsteps(maxcol) / 16;
+    // temporarily store offsets in the pointer fields
+    e.bnd = (int32_t*)(uintptr_t)bnd_ints;
+    bnd_ints += 2 * (size_t)e.bnd_pitch;
+    if (want_trace) {
+      e.dirs = (uint32_t*)(uintptr_t)(dir_words + 1);  // +1 so that offset 0 is not nullptr
+      dir_words += exact_dir_words(s.Q, maxcol);
+      e.ops = (uint8_t*)(uintptr_t)ops_bytes;
+      ops_bytes += ((size_t)s.Q + s.T + 15) / 16 * 16;
+    } else {
+      e.dirs = nullptr;
+      e.ops = nullptr;
+    }
+  }
+  int rc;
+  if ((rc = c.sym.ensure(std::max<size_t>(pool.size() * 2, 16)))) return rc;
+  if ((rc = c.pairs.ensure(n * sizeof(ExactPair)))) return rc;
+  if ((rc = c.outs.ensure(n * sizeof(ExactOut)))) return rc;
+  if ((rc = c.bnd.ensure(std::max<size_t>(bnd_ints * 4, 16)))) return rc;
+  if (want_trace) {
+    if ((rc = c.dirs.ensure(std::max<size_t>(dir_words * 4, 16)))) return rc;
+    if ((rc = c.ops.ensure(std::max<size_t>(ops_bytes, 16)))) return rc;
+  }
+  for (size_t i = 0; i < n; i++) {
+    ExactPair& e = hp[i];
+    e.q = (const uint16_t*)c.sym.p + qoff[i];
+    e.t = (const uint16_t*)c.sym.p + toff[i];
+    e.bnd = (int32_t*)c.bnd.p + (uintptr_t)e.bnd;
+    if (want_trace) {
+      e.dirs = (uint32_t*)c.dirs.p + ((uintptr_t)e.dirs - 1);
+      e.ops = (uint8_t*)c.ops.p + (uintptr_t)e.ops;
+    }
+  }
+  if (!pool.empty()) HIPCK(hipMemcpyAsync(c.sym.p, pool.data(), pool.size() * 2, hipMemcpyHostToDevice, c.stream));
+  HIPCK(hipMemcpyAsync(c.pairs.p, hp.data(), n * sizeof(ExactPair), hipMemcpyHostToDevice, c.stream));
+  HIPCK(hipEventRecord(c.ev2, c.stream));
+  HIPCK(launch_exact((const ExactPair*)c.pairs.p, (ExactOut*)c.outs.p, (uint32_t)n, sc, c.stream));
+  if (want_trace) HIPCK(launch_walk((const ExactPair*)c.pairs.p, (ExactOut*)c.outs.p, (uint32_t)n, sc, c.stream));
+  HIPCK(hipEventRecord(c.ev3, c.stream));
+  std::vector<ExactOut> ho(n);
+  HIPCK(hipMemcpyAsync(ho.data(), c.outs.p, n * sizeof(ExactOut), hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipStreamSynchronize(c.stream));
+  float ms = 0;
+  HIPCK(hipEventElapsedTime(&ms, c.ev2, c.ev3));
+  c.stats.exact_kernel_ms += ms;
+  std::vector<uint8_t> hops;
+  if (want_trace && ops_bytes) {
+    // copy only what the walkers wrote
+    hops.resize(ops_bytes);
+    size_t lo = 0;
+    while (lo < n) {  // coalesce into a few large copies: ops buffers are contiguous per pair
+      size_t hi = lo;
+      size_t start = (uint8_t*)hp[lo].ops - (uint8_t*)c.ops.p;
+      size_t endb = start;
+      while (hi < n) {
+        size_t s0 = (uint8_t*)hp[hi].ops - (uint8_t*)c.ops.p;
+        if (s0 - endb > (1u << 16)) break;
+        endb = s0 + ho[hi].nops;
+        hi++;
+      }
+      if (endb > start) HIPCK(hipMemcpyAsync(hops.data() + start, (uint8_t*)c.ops.p + start, endb - start, hipMemcpyDeviceToHost, c.stream));
+      lo = hi;
+    }
+    HIPCK(hipStreamSynchronize(c.stream));
+  }
+  for (size_t i = 0; i < n; i++) {
+    PairOut& o = outs[begin + i];
+    o.score = ho[i].score;
+    o.bx = ho[i].bx;
+    o.bj = ho[i].bj;
+    c.stats.exact_cells += (uint64_t)specs[begin + i].Q * specs[begin + i].T;
+    if (want_trace && ho[i].nops) {
+      size_t s0 = (uint8_t*)hp[i].ops - (uint8_t*)c.ops.p;
+      o.ops.assign(hops.begin() + s0, hops.begin() + s0 + ho[i].nops);
+    }
+  }
+  return SW_OK;
+}
+
+int run_exact(const PairSpec* specs, size_t n, Scoring sc, bool want_trace, PairOut* outs) {
+  Context& c = g_ctx;
+  size_t begin = 0;
+  while (begin < n) {
+    size_t end = begin, bytes = 0;
+    while (end < n) {
+      PathParams pp = resolve_path(specs[end].path, specs[end].Q, specs[end].T);
+      size_t b = (size_t)specs[end].Q * 2 + (size_t)specs[end].T * 10 + 256;
+      if (want_trace) b += exact_dir_words(specs[end].Q, std::max(pp.Tlim, pp.T0)) * 4 + specs[end].Q + specs[end].T;
+      if (end > begin && (bytes + b > c.scratch_budget || end - begin >= (1u << 20))) break;
+      bytes += b;
+      end++;
+    }
+    int rc = run_exact_chunk(specs, begin, end, sc, want_trace, outs);
+    if (rc) return rc;
+    begin = end;
+  }
+  return SW_OK;
+}
+
+// ---- Result boxes ------------------------------------------------------------------------------------------
+struct ResultBox {
+  Result r;
+  int32_t score32;
+  uint32_t magic;
+};
+constexpr uint32_t kMagic = 0x53574850u;  // "SWHP"
+std::mutex g_str_mu;
+std::unordered_map<char*, ResultBox*> g_live_strings;  // strings still owned by a live Result
+
+char* dup_string(const std::string& s) {
+  char* p = (char*)malloc(s.size() + 1);
+  if (!p) return nullptr;
+  memcpy(p, s.data(), s.size());
+  p[s.size()] = 0;
+  return p;
+}
+
+// Builds the two aligned strings from the walker's ops (rust/src/algorithm/mod.rs:677-706: the recursion
+// pushes after returning, so the first cell visited is the LAST column).
+void build_alignment(const std::vector<uint32_t>& q, const std::vector<uint32_t>& t, const PairOut& o,
+                     std::string& qa, std::string& ta) {
+  qa.clear();
+  ta.clear();
+  uint32_t x = o.bx, j = o.bj;
+  // positions at the start of the alignment
+  uint32_t nx = 0, nj = 0;
+  for (uint8_t op : o.ops) {
+    if (op == 0) { nx++; nj++; }
+    else if (op == 1) nx++;
+    else nj++;
+  }
+  uint32_t cx = x - nx, cj = j - nj;  // 0-based index of the first aligned symbol
+  for (size_t k = o.ops.size(); k-- > 0;) {
+    uint8_t op = o.ops[k];
+    if (op == 0) { encode_utf8(q[cx++], qa); encode_utf8(t[cj++], ta); }
+    else if (op == 1) { encode_utf8(q[cx++], qa); ta.push_back('-'); }
+    else { qa.push_back('-'); encode_utf8(t[cj++], ta); }
+  }
+}
+
+Result* box_result(const std::string& qa, const std::string& ta, int path, const PairOut& o) {
+  ResultBox* b = (ResultBox*)calloc(1, sizeof(ResultBox));
+  if (!b) return nullptr;
+  b->r.query_ptr = dup_string(qa);
+  b->r.target_ptr = dup_string(ta);
+  if (!b->r.query_ptr || !b->r.target_ptr) {
+    free(b->r.query_ptr);
+    free(b->r.target_ptr);
+    free(b);
+    return nullptr;
+  }
+  b->magic = kMagic;
+  if (path == SW_PATH_STRAIGHT) {  // rust/src/lib.rs:70: (.., 0, x, y)
+    b->score32 = 0;
+    b->r.score = 0;
+    b->r.max_x = o.bx;
+    b->r.max_y = o.bj;
+  } else {                         // rust/src/lib.rs:135, algorithm/mod.rs:444: (.., max, x-1, y-x-1), wrapping
+    b->score32 = o.score;
+    b->r.score = (uint16_t)o.score;
+    b->r.max_x = (uint64_t)o.bx - 1;
+    b->r.max_y = (uint64_t)o.bj - 1;
+  }
+  std::lock_guard<std::mutex> lk(g_str_mu);
+  g_live_strings[b->r.query_ptr] = b;
+  g_live_strings[b->r.target_ptr] = b;
+  return &b->r;
+}
+
+Scoring to_scoring(AlignmentScores s) {
+  return Scoring{(int)(int16_t)s.match, (int)(int16_t)s.miss, (int)(int16_t)s.gap};
+}
+
+struct Decoded {
+  std::vector<uint32_t> cps;
+  std::vector<uint16_t> sym;
+};
+bool decode(const char* s, Decoded& d) {
+  if (!s || !decode_utf8(s, d.cps)) return false;
+  d.sym.resize(d.cps.size());
+  for (size_t i = 0; i < d.cps.size(); i++) d.sym[i] = (uint16_t)d.cps[i];
+  return true;
+}
+
+// The reference panics (-> NULL) on the ring path when gap == 0 (rust/src/algorithm/mod.rs:236-238).
+bool ring_div_by_zero(int path, uint32_t Q, uint32_t T, Scoring sc) {
+  return path == SW_PATH_LOW_MEMORY && !((uint64_t)T < 2ull * Q) && sc.gap == 0;
+}
+
+int align_many(const char* const* queries, const char* const* targets, size_t n, AlignmentScores as, int path,
+               Result** out) {
+  if (n == 0) return SW_OK;
+  if (!queries || !targets || !out) return fail(SW_E_ARG, "null argument");
+  if (path < 0 || path > 2) return fail(SW_E_ARG, "bad path");
+  const Scoring sc = to_scoring(as);
+  std::vector<Decoded> dq(n), dt(n);
+  std::vector<PairSpec> specs;
+  std::vector<size_t> idx;
+  specs.reserve(n);
+  for (size_t i = 0; i < n; i++) {
+    out[i] = nullptr;
+    if (!decode(queries[i], dq[i]) || !decode(targets[i], dt[i])) continue;  // bindings.rs:125 unwrap -> NULL
+    if (dq[i].sym.size() >= 0x7fffff00u || dt[i].sym.size() >= 0x7fffff00u) continue;
+    if (ring_div_by_zero(path, (uint32_t)dq[i].sym.size(), (uint32_t)dt[i].sym.size(), sc)) continue;
+    specs.push_back(PairSpec{dq[i].sym.data(), (uint32_t)dq[i].sym.size(), dt[i].sym.data(), (uint32_t)dt[i].sym.size(), path});
+    idx.push_back(i);
+  }
+  std::vector<PairOut> po(specs.size());
+  {
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    int rc = ctx_init_locked(-1);
+    if (rc) return rc;
+    rc = run_exact(specs.data(), specs.size(), sc, true, po.data());
+    if (rc) return rc;
+  }
+  std::string qa, ta;
+  for (size_t k = 0; k < specs.size(); k++) {
+    size_t i = idx[k];
+    build_alignment(dq[i].cps, dt[i].cps, po[k], qa, ta);
+    out[i] = box_result(qa, ta, path, po[k]);
+  }
+  return SW_OK;
+}
+
+Result* align_one(char* query, char* target, AlignmentScores as, int path) {
+  Result* r = nullptr;
+  const char* q = query;
+  const char* t = target;
+  int rc = align_many(&q, &t, 1, as, path, &r);
+  if (rc != SW_OK) return nullptr;
+  if (!r && g_err.empty()) g_err = "invalid input (UTF-8) or reference panic condition";
+  return r;
+}
+
+}  // namespace
+
+// ================================================================================================
+// include/sw.h
+// ================================================================================================
+extern "C" {
+
+Result* find_alignment_low_memory(char* query, char* target, AlignmentScores s) {
+  return align_one(query, target, s, SW_PATH_LOW_MEMORY);
+}
+Result* find_alignment_simd(char* query, char* target, AlignmentScores s) {
+  return align_one(query, target, s, SW_PATH_SIMD);
+}
+Result* find_alignment_sequential_straight(char* query, char* target, AlignmentScores s) {
+  return align_one(query, target, s, SW_PATH_STRAIGHT);
+}
+Result* find_alignment_parallel(char*, char*, size_t, AlignmentScores) {
+  g_err = "find_alignment_parallel is declared by rust/header/sw.h but not defined by the reference";
+  return nullptr;
+}
+Result* find_alignment_sequential(char*, char*, AlignmentScores) {
+  g_err = "find_alignment_sequential is declared by rust/header/sw.h but not defined by the reference";
+  return nullptr;
+}
+
+void free_alignment_result(Result* result) {
+  if (!result) return;
+  ResultBox* b = (ResultBox*)result;
+  if (b->magic != kMagic) return;  // not ours (or already freed): leave it alone
+  {
+    std::lock_guard<std::mutex> lk(g_str_mu);
+    if (b->r.query_ptr) g_live_strings.erase(b->r.query_ptr);
+    if (b->r.target_ptr) g_live_strings.erase(b->r.target_ptr);
+  }
+  free(b->r.query_ptr);
+  free(b->r.target_ptr);
+  b->magic = 0;
+  free(b);
+}
+
+void free_c_string(char* str) {
+  if (!str) return;
+  {
+    std::lock_guard<std::mutex> lk(g_str_mu);
+    auto it = g_live_strings.find(str);
+    if (it != g_live_strings.end()) {  // detach from its Result so free_alignment_result will not free it again
+      ResultBox* b = it->second;
+      if (b->r.query_ptr == str) b->r.query_ptr = nullptr;
+      if (b->r.target_ptr == str) b->r.target_ptr = nullptr;
+      g_live_strings.erase(it);
+    }
+  }
+  free(str);
+}
+
+// ================================================================================================
+// include/sw_hip.h
+// ================================================================================================
+int sw_hip_init(int device) {
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  return ctx_init_locked(device);
+}
+const char* sw_hip_last_error(void) { return g_err.c_str(); }
+const char* sw_hip_version(void) { return "libsw_hip 0.1 (gfx950; exact int32 wavefront + packed-int16 inter-task kernels)"; }
+
+int32_t sw_result_score32(const Result* result) {
+  if (!result) return 0;
+  const ResultBox* b = (const ResultBox*)result;
+  return b->magic == kMagic ? b->score32 : (int32_t)(int16_t)result->score;
+}
+
+int sw_align_batch(const char* const* queries, const char* const* targets, size_t n_pairs, AlignmentScores scores,
+                   int path, Result** out) {
+  return align_many(queries, targets, n_pairs, scores, path, out);
+}
+
+int sw_hip_last_stats(sw_kernel_stats* out) {
+  if (!out) return fail(SW_E_ARG, "null argument");
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  *out = g_ctx.stats;
+  return SW_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// resident database + top-k
+// ================================================================================================
+struct sw_db {
+  uint64_t n = 0, residues = 0;
+  std::vector<uint64_t> off;       // n + 1
+  std::string flat;                // original bytes
+  std::vector<uint8_t> packed_ok;  // per target: only A, C, G, T
+  // packed part
+  std::vector<uint32_t> slot_target;  // per slot: database index or UINT32_MAX
+  std::vector<ScoreGroup> groups;
+  uint32_t* d_words = nullptr;
+  uint32_t* d_lens = nullptr;
+  ScoreGroup* d_groups = nullptr;
+  std::vector<uint32_t> generic;  // targets scored by the exact kernel only
+  uint32_t max_len = 0;
+};
+
+namespace {
+
+inline int nt_code(unsigned char ch) {
+  switch (ch) {
+    case 'A': return 0;
+    case 'C': return 1;
+    case 'G': return 2;
+    case 'T': return 3;
+    default: return -1;
+  }
+}
+
+void db_release(sw_db* db) {
+  if (!db) return;
+  if (db->d_words) (void)hipFree(db->d_words);
+  if (db->d_lens) (void)hipFree(db->d_lens);
+  if (db->d_groups) (void)hipFree(db->d_groups);
+  delete db;
+}
+
+sw_db* db_build(std::string&& flat, std::vector<uint64_t>&& off) {
+  sw_db* db = new sw_db;
+  db->n = off.size() - 1;
+  db->flat = std::move(flat);
+  db->off = std::move(off);
+  db->residues = db->off.back() - db->off.front();
+  db->packed_ok.assign(db->n, 1);
+  std::vector<uint32_t> packable;
+  for (uint64_t i = 0; i < db->n; i++) {
+    uint64_t len = db->off[i + 1] - db->off[i];
+    if (len >= 0x7fffff00ull) {
+      db_release(db);
+      fail(SW_E_ARG, "sequence too long");
+      return nullptr;
+    }
+    db->max_len = std::max<uint32_t>(db->max_len, (uint32_t)len);
+    bool ok = true;
+    const unsigned char* s = (const unsigned char*)db->flat.data() + db->off[i];
+    for (uint64_t k = 0; k < len; k++) {
+      unsigned char ch = s[k];
+      if (ch >= 0x80 || ch == 0) {  // bytes are treated as one symbol each: ASCII only
+        if (ch == 0) {
+          db_release(db);
+          fail(SW_E_ARG, "NUL byte inside a sequence");
+          return nullptr;
+        }
+      }
+      if (nt_code(ch) < 0) ok = false;
+    }
+    db->packed_ok[i] = ok;
+    if (ok && len > 0) packable.push_back((uint32_t)i);
+    else db->generic.push_back((uint32_t)i);
+  }
+  // length-sorted (descending, stable on index) groups of 128
+  std::stable_sort(packable.begin(), packable.end(), [&](uint32_t a, uint32_t b) {
+    return (db->off[a + 1] - db->off[a]) > (db->off[b + 1] - db->off[b]);
+  });
+  const size_t ngroups = (packable.size() + kGroupTargets - 1) / kGroupTargets;
+  db->groups.resize(ngroups);
+  db->slot_target.assign(ngroups * kGroupTargets, UINT32_MAX);
+  std::vector<uint32_t> lens(ngroups * kGroupTargets, 0);
+  size_t total_words = 0;
+  for (size_t g = 0; g < ngroups; g++) {
+    uint32_t maxlen = 0;
+    for (int s = 0; s < kGroupTargets; s++) {
+      size_t k = g * kGroupTargets + s;
+      if (k >= packable.size()) break;
+      uint32_t ti = packable[k];
+      uint32_t len = (uint32_t)(db->off[ti + 1] - db->off[ti]);
+      db->slot_target[k] = ti;
+      lens[k] = len;
+      maxlen = std::max(maxlen, len);
+    }
+    db->groups[g].word_off = total_words;
+    db->groups[g].nstrips = (maxlen + kScoreR - 1) / kScoreR;
+    db->groups[g].first_slot = (uint32_t)(g * kGroupTargets);
+    total_words += (size_t)db->groups[g].nstrips * kGroupTargets;
+  }
+  std::vector<uint32_t> words(std::max<size_t>(total_words, 1), 0);
+  for (size_t g = 0; g < ngroups; g++) {
+    for (int s = 0; s < kGroupTargets; s++) {
+      size_t k = g * kGroupTargets + s;
+      uint32_t ti = db->slot_target[k];
+      if (ti == UINT32_MAX) continue;
+      const unsigned char* seq = (const unsigned char*)db->flat.data() + db->off[ti];
+      const uint32_t len = lens[k];
+      const int half = s / 64, lane = s % 64;
+      for (uint32_t strip = 0; strip * kScoreR < len; strip++) {
+        uint32_t w = 0;
+        for (int r = 0; r < kScoreR; r++) {
+          uint32_t col = strip * kScoreR + r;
+          if (col < len) w |= (uint32_t)nt_code(seq[col]) << (2 * r);
+        }
+        words[db->groups[g].word_off + ((size_t)strip * 2 + half) * 64 + lane] = w;
+      }
+    }
+  }
+  if (ngroups) {
+    if (hipMalloc(&db->d_words, words.size() * 4) != hipSuccess || hipMalloc(&db->d_lens, lens.size() * 4) != hipSuccess ||
+        hipMalloc(&db->d_groups, ngroups * sizeof(ScoreGroup)) != hipSuccess) {
+      db_release(db);
+      fail(SW_E_NOMEM, "hipMalloc failed for the database");
+      return nullptr;
+    }
+    if (hipMemcpy(db->d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(db->d_lens, lens.data(), lens.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(db->d_groups, db->groups.data(), ngroups * sizeof(ScoreGroup), hipMemcpyHostToDevice) != hipSuccess) {
+      db_release(db);
+      fail(SW_E_HIP, "hipMemcpy failed for the database");
+      return nullptr;
+    }
+  }
+  return db;
+}
+
+struct QueryPrep {
+  Decoded d;
+  bool acgt = true;
+  std::vector<uint32_t> qwords;
+};
+
+bool fast_domain(Scoring sc) {
+  return sc.match > 0 && sc.miss < 0 && sc.gap < 0 && sc.match <= 16384 && sc.miss >= -16384 && sc.gap >= -16384;
+}
+
+// scores of every database sequence against one query, reference-exact (low_memory semantics)
+int db_scores_locked(sw_db* db, const QueryPrep& qp, Scoring sc, std::vector<int32_t>& scores,
+                     std::vector<std::vector<uint16_t>>& tsym_cache) {
+  Context& c = g_ctx;
+  const uint32_t Q = (uint32_t)qp.d.sym.size();
+  scores.assign(db->n, 0);
+  std::vector<uint32_t> rerun(db->generic);
+  const bool fast = qp.acgt && fast_domain(sc) && Q > 0 && !db->groups.empty();
+  if (!fast) {
+    rerun.resize(db->n);
+    std::iota(rerun.begin(), rerun.end(), 0u);
+  } else {
+    const uint32_t nblk = (Q + kScoreB - 1) / kScoreB;
+    const size_t Qpad = (size_t)nblk * kScoreB;
+    const int W = score_waves_per_group();
+    const int per_cu = std::max(1, 16 / W);
+    const int nwg = (int)std::min<size_t>(db->groups.size(), (size_t)c.cus * per_cu);
+    const size_t gb_stride = 2 * Qpad * 64;
+    int rc;
+    if ((rc = c.qwords.ensure(qp.qwords.size() * 4))) return rc;
+    if ((rc = c.slot_scores.ensure(db->slot_target.size() * 4))) return rc;
+    if ((rc = c.gbound.ensure((size_t)nwg * gb_stride * 4))) return rc;
+    if ((rc = c.ticket.ensure(256))) return rc;
+    HIPCK(hipMemcpyAsync(c.qwords.p, qp.qwords.data(), qp.qwords.size() * 4, hipMemcpyHostToDevice, c.stream));
+    HIPCK(hipMemsetAsync(c.ticket.p, 0, 256, c.stream));
+    ScoreParams p{};
+    p.words = db->d_words;
+    p.groups = db->d_groups;
+    p.lens = db->d_lens;
+    p.qwords = (const uint32_t*)c.qwords.p;
+    p.Q = Q;
+    p.n_groups = (uint32_t)db->groups.size();
+    p.slot_scores = (int32_t*)c.slot_scores.p;
+    p.gbound = (uint32_t*)c.gbound.p;
+    p.gbound_stride = gb_stride;
+    p.ticket = (uint32_t*)c.ticket.p;
+    p.match = sc.match;
+    p.miss = sc.miss;
+    p.gap = sc.gap;
+    HIPCK(hipEventRecord(c.ev0, c.stream));
+    HIPCK(launch_score(p, nwg, c.stream));
+    HIPCK(hipEventRecord(c.ev1, c.stream));
+    std::vector<int32_t> slot(db->slot_target.size());
+    HIPCK(hipMemcpyAsync(slot.data(), c.slot_scores.p, slot.size() * 4, hipMemcpyDeviceToHost, c.stream));
+    HIPCK(hipStreamSynchronize(c.stream));
+    float ms = 0;
+    HIPCK(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+    c.stats.score_kernel_ms += ms;
+    c.stats.score_launches += 1;
+    const uint32_t Qp = roundup64(Q);
+    for (size_t k = 0; k < slot.size(); k++) {
+      uint32_t ti = db->slot_target[k];
+      if (ti == UINT32_MAX) continue;
+      const uint32_t T = (uint32_t)(db->off[ti + 1] - db->off[ti]);
+      c.stats.score_cells += (uint64_t)Q * T;
+      const int32_t s = slot[k];
+      const bool full = (uint64_t)T < 2ull * Q;
+      bool need = false;
+      if (s >= 32767) need = true;                                   // int16 saturation -> int32 re-run
+      if (!full && T < Qp) need = true;                              // ring path with T < Qp (quirk Q2)
+      if (full && T % 64 == 0 && roundup64(T) >= Qp && s < sc.match) need = true;  // only H(1,T) can score
+      if (need) rerun.push_back(ti);
+      else scores[ti] = s;
+    }
+  }
+  if (!rerun.empty()) {
+    std::vector<PairSpec> specs(rerun.size());
+    tsym_cache.resize(rerun.size());
+    for (size_t k = 0; k < rerun.size(); k++) {
+      uint32_t ti = rerun[k];
+      const unsigned char* s = (const unsigned char*)db->flat.data() + db->off[ti];
+      uint32_t T = (uint32_t)(db->off[ti + 1] - db->off[ti]);
+      tsym_cache[k].assign(s, s + T);
+      specs[k] = PairSpec{qp.d.sym.data(), Q, tsym_cache[k].data(), T, SW_PATH_LOW_MEMORY};
+    }
+    std::vector<PairOut> po(rerun.size());
+    int rc = run_exact(specs.data(), specs.size(), sc, false, po.data());
+    if (rc) return rc;
+    for (size_t k = 0; k < rerun.size(); k++) scores[rerun[k]] = po[k].score;
+    c.stats.rerun_pairs += (uint32_t)rerun.size();
+  }
+  return SW_OK;
+}
+
+bool prep_query(const char* query, QueryPrep& qp) {
+  if (!decode(query, qp.d)) return false;
+  const size_t Q = qp.d.sym.size();
+  qp.qwords.assign((Q + 15) / 16 + 1, 0);
+  for (size_t i = 0; i < Q; i++) {
+    int code = qp.d.cps[i] < 128 ? nt_code((unsigned char)qp.d.cps[i]) : -1;
+    if (code < 0) {
+      qp.acgt = false;
+      code = 0;
+    }
+    qp.qwords[i / 16] |= (uint32_t)code << (2 * (i % 16));
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+sw_db* sw_db_create(const char* flat, const uint64_t* offsets, uint64_t n) {
+  if ((!flat && n) || !offsets) {
+    fail(SW_E_ARG, "null argument");
+    return nullptr;
+  }
+  for (uint64_t i = 0; i < n; i++)
+    if (offsets[i + 1] < offsets[i]) {
+      fail(SW_E_ARG, "offsets must be non-decreasing");
+      return nullptr;
+    }
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  if (ctx_init_locked(-1)) return nullptr;
+  std::vector<uint64_t> off(n + 1);
+  for (uint64_t i = 0; i <= n; i++) off[i] = offsets[i] - offsets[0];
+  std::string f(flat + offsets[0], flat + offsets[n]);
+  return db_build(std::move(f), std::move(off));
+}
+
+sw_db* sw_db_load_fasta(const char* path) {
+  if (!path) {
+    fail(SW_E_ARG, "null path");
+    return nullptr;
+  }
+  std::ifstream in(path, std::ios::binary);
+  if (!in) {
+    fail(SW_E_ARG, std::string("cannot open ") + path);
+    return nullptr;
+  }
+  // cli/__main__.py:19-34: split on '>', first line is the header, the remaining lines are concatenated
+  std::string flat, line;
+  std::vector<uint64_t> off;
+  bool have = false;
+  while (std::getline(in, line)) {
+    while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
+    if (!line.empty() && line[0] == '>') {
+      off.push_back(flat.size());
+      have = true;
+    } else if (have) {
+      flat += line;
+    }
+  }
+  if (!have) {
+    fail(SW_E_ARG, "no FASTA records");
+    return nullptr;
+  }
+  off.push_back(flat.size());
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  if (ctx_init_locked(-1)) return nullptr;
+  return db_build(std::move(flat), std::move(off));
+}
+
+void sw_db_free(sw_db* db) {
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  db_release(db);
+}
+uint64_t sw_db_size(const sw_db* db) { return db ? db->n : 0; }
+uint64_t sw_db_residues(const sw_db* db) { return db ? db->residues : 0; }
+
+int sw_db_scores(sw_db* db, const char* query, AlignmentScores as, int32_t* scores_out) {
+  if (!db || !query || !scores_out) return fail(SW_E_ARG, "null argument");
+  QueryPrep qp;
+  if (!prep_query(query, qp)) return fail(SW_E_ARG, "query is not valid UTF-8");
+  const Scoring sc = to_scoring(as);
+  std::vector<int32_t> scores;
+  std::vector<std::vector<uint16_t>> cache;
+  std::lock_guard<std::mutex> lk(g_ctx.mu);
+  int rc = ctx_init_locked(-1);
+  if (rc) return rc;
+  g_ctx.stats = sw_kernel_stats{};
+  rc = db_scores_locked(db, qp, sc, scores, cache);
+  if (rc) return rc;
+  memcpy(scores_out, scores.data(), scores.size() * sizeof(int32_t));
+  return SW_OK;
+}
+
+int sw_db_search_topk(sw_db* db, const char* query, AlignmentScores as, int k, sw_hit* hits, int* n_hits) {
+  if (!db || !query || !hits || !n_hits || k < 0) return fail(SW_E_ARG, "bad argument");
+  *n_hits = 0;
+  QueryPrep qp;
+  if (!prep_query(query, qp)) return fail(SW_E_ARG, "query is not valid UTF-8");
+  const Scoring sc = to_scoring(as);
+  std::vector<int32_t> scores;
+  std::vector<std::vector<uint16_t>> cache;
+  std::vector<PairOut> po;
+  std::vector<uint32_t> order;
+  std::vector<std::vector<uint16_t>> tsym;
+  {
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    int rc = ctx_init_locked(-1);
+    if (rc) return rc;
+    g_ctx.stats = sw_kernel_stats{};
+    rc = db_scores_locked(db, qp, sc, scores, cache);
+    if (rc) return rc;
+    // top-k: score descending, then database index ascending (declared replacement of the reference's
+    // arrival-order ties, cli/__main__.py:171)
+    const size_t kk = std::min<size_t>((size_t)k, db->n);
+    order.resize(db->n);
+    std::iota(order.begin(), order.end(), 0u);
+    auto cmp = [&](uint32_t a, uint32_t b) { return scores[a] != scores[b] ? scores[a] > scores[b] : a < b; };
+    std::partial_sort(order.begin(), order.begin() + kk, order.end(), cmp);
+    order.resize(kk);
+    std::vector<PairSpec> specs(kk);
+    tsym.resize(kk);
+    for (size_t i = 0; i < kk; i++) {
+      uint32_t ti = order[i];
+      const unsigned char* s = (const unsigned char*)db->flat.data() + db->off[ti];
+      uint32_t T = (uint32_t)(db->off[ti + 1] - db->off[ti]);
+      tsym[i].assign(s, s + T);
+      specs[i] = PairSpec{qp.d.sym.data(), (uint32_t)qp.d.sym.size(), tsym[i].data(), T, SW_PATH_LOW_MEMORY};
+    }
+    po.resize(kk);
+    rc = run_exact(specs.data(), kk, sc, true, po.data());
+    if (rc) return rc;
+  }
+  std::string qa, ta;
+  std::vector<uint32_t> tcps;
+  for (size_t i = 0; i < order.size(); i++) {
+    tcps.assign(tsym[i].begin(), tsym[i].end());
+    build_alignment(qp.d.cps, tcps, po[i], qa, ta);
+    if (po[i].score != scores[order[i]])
+      return fail(SW_E_HIP, "internal: score kernel and exact kernel disagree on target " + std::to_string(order[i]) + " (" +
+                                std::to_string(scores[order[i]]) + " vs " + std::to_string(po[i].score) + ")");
+    sw_hit& h = hits[i];
+    h.target_index = order[i];
+    h.score = po[i].score;
+    h.length = (uint32_t)qa.size();
+    h.max_x = (uint64_t)po[i].bx - 1;
+    h.max_y = (uint64_t)po[i].bj - 1;
+    h.query_aln = dup_string(qa);
+    h.target_aln = dup_string(ta);
+  }
+  *n_hits = (int)order.size();
+  return SW_OK;
+}
+
+void sw_hits_free(sw_hit* hits, int n_hits) {
+  if (!hits) return;
+  for (int i = 0; i < n_hits; i++) {
+    free(hits[i].query_aln);
+    free(hits[i].target_aln);
+    hits[i].query_aln = hits[i].target_aln = nullptr;
+  }
+}
+
+float sw_hip_benchmark_cups(void) {
+  // internal/worker/worker_rust_benchmark.go:38-68 measures one CPU thread on one synthetic pair; a GPU
+  // worker runs work packages through the batch path, so that is what is timed here: 1 query (4096 nt) x
+  // 16384 targets (1024 nt) of seeded uniform DNA, match 1 / mismatch -1 / gap -2 (the reference's
+  // benchmark scores, worker_rust_benchmark.go:10-18).  Returned as an integer-valued float32 because
+  // the master's field is a pydantic int (master/api_models/worker.py:7-16).
+  const uint32_t nQ = 4096, nT = 1024, n = 16384;
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() {
+    st += 0x9E3779B97F4A7C15ull;
+    uint64_t z = st;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  };
+  const char nt[4] = {'A', 'C', 'G', 'T'};
+  std::string flat((size_t)n * nT, 'A'), query(nQ, 'A');
+  for (auto& ch : flat) ch = nt[rnd() & 3];
+  for (auto& ch : query) ch = nt[rnd() & 3];
+  std::vector<uint64_t> off(n + 1);
+  for (uint32_t i = 0; i <= n; i++) off[i] = (uint64_t)i * nT;
+  sw_db* db = sw_db_create(flat.data(), off.data(), n);
+  if (!db) return 0.0f;
+  std::vector<int32_t> sc(n);
+  AlignmentScores as{(uint16_t)-2, 1, (uint16_t)-1};
+  float best = 0.0f;
+  for (int rep = 0; rep < 3; rep++) {
+    auto t0 = std::chrono::steady_clock::now();
+    if (sw_db_scores(db, query.c_str(), as, sc.data()) != SW_OK) {
+      sw_db_free(db);
+      return 0.0f;
+    }
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    float cups = (float)((double)nQ * nT * n / secs);
+    best = std::max(best, cups);
+  }
+  sw_db_free(db);
+  return (float)(double)(uint64_t)best;
+}
+
+}  // extern "C"

@@ -1,0 +1,207 @@
+// dlsa_amd/csrc/sw_score.hip -- the inter-task (many targets, one query) score kernel for gfx950.
+//
+// What it replaces: for every (query, target) pair of a database search, the score-matrix fill and the
+// maximum of rust/src/algorithm/mod.rs:66-202 / :204-445 (one cgo call per pair in the reference,
+// internal/worker/worker_impl.go:108-168).  Only the best score per target leaves the kernel; end
+// coordinates and alignments of the reported hits come from the exact kernel (sw_exact.hip).
+//
+// Design (MI355X-first, nothing like the reference's anti-diagonal CPU SIMD):
+//  * one 32-bit lane = TWO targets (packed int16 halves), one wavefront = 128 length-sorted targets;
+//  * a wave keeps R = 16 target COLUMNS of its 128 targets in registers and walks down the query, so the
+//    query residue of a row is wave-uniform: the substitution scores of a row are four pre-built
+//    register tables (one per query nucleotide) selected by a scalar branch -- no LDS profile lookup and
+//    no VALU compare per cell;
+//  * per cell 4.5 packed VALU instructions: v_pk_max_i16(left, up), v_pk_sub_u16 clamp (the unsigned
+//    saturating subtract of |gap| is also the max(.,0)), v_pk_add_i16 clamp (diag + s, saturation = the
+//    overflow detector), v_pk_max_i16, and the running maximum on every second column only (max(left,up)
+//    of an odd column covers the new even-column cell of this row and the odd-column cell of the previous
+//    row);
+//  * the W waves of a workgroup own consecutive 16-column strips and run as a software pipeline over
+//    16-row blocks; the H column between neighbouring strips travels through LDS (double-buffered),
+//    one s_barrier per block; longer targets take several passes, the boundary column between passes
+//    goes through a per-workgroup HBM buffer (read back L1-bypassing);
+//  * persistent workgroups pull (query, group) units from an atomic ticket.
+//
+// Saturation: diag + s uses the clamp bit, so a lane whose true maximum exceeds 32766 reports 32767 and
+// the host re-runs that pair with the int32 exact kernel.
+#include "sw_internal.h"
+
+namespace swhip {
+
+namespace {
+
+typedef short s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u2 __attribute__((ext_vector_type(2)));
+
+constexpr int R = kScoreR;
+constexpr int B = kScoreB;
+
+__device__ __forceinline__ s2 pk_max(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s2 pk_add_sat(s2 a, s2 b) { return __builtin_elementwise_add_sat(a, b); }
+__device__ __forceinline__ s2 pk_subu_sat(s2 a, s2 b) {
+  return (s2)__builtin_elementwise_sub_sat((u2)a, (u2)b);
+}
+__device__ __forceinline__ s2 as_s2(uint32_t v) { return __builtin_bit_cast(s2, v); }
+__device__ __forceinline__ uint32_t as_u32(s2 v) { return __builtin_bit_cast(uint32_t, v); }
+
+// One query row over the wave's R columns.  H[r] holds H(x-1, col r) on entry and H(x, col r) on exit.
+__device__ __forceinline__ void sw_row(s2 (&H)[R], const s2 (&tab)[R], s2& best, s2 left_in, s2 diag_in,
+                                       s2 gapabs) {
+  s2 hl = left_in, hd = diag_in;
+#pragma unroll
+  for (int r = 0; r < R; r++) {
+    const s2 hu = H[r];
+    const s2 m = pk_max(hl, hu);
+    if (r & 1) best = pk_max(best, m);
+    const s2 t = pk_subu_sat(m, gapabs);     // max(left, up) + gap, floored at 0
+    const s2 d = pk_add_sat(hd, tab[r]);     // diag + s, saturating at 32767
+    const s2 h = pk_max(t, d);               // >= 0 because t >= 0
+    hd = hu;
+    hl = h;
+    H[r] = h;
+  }
+}
+
+template <int W>
+__global__ void __launch_bounds__(W * 64) sw_score_kernel(ScoreParams p) {
+  __shared__ uint32_t lds[W * 2 * B * 64];  // [wave][block parity][row][lane]: H column entering a wave
+  __shared__ uint32_t s_unit;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const uint32_t Q = p.Q;
+  const uint32_t nblk = (Q + B - 1) / B;
+  const uint32_t Qpad = nblk * B;
+  uint32_t* gb = p.gbound + (size_t)blockIdx.x * p.gbound_stride;  // [2][Qpad][64]
+  const s2 gapabs = {(short)(-p.gap), (short)(-p.gap)};
+  const short mt = (short)p.match, ms = (short)p.miss;
+
+  for (;;) {
+    if (threadIdx.x == 0) s_unit = atomicAdd(p.ticket, 1u);
+    __syncthreads();
+    const uint32_t unit = s_unit;
+    __syncthreads();
+    if (unit >= p.n_groups) break;
+    const ScoreGroup G = p.groups[unit];
+    const uint32_t Tlo = p.lens[G.first_slot + lane], Thi = p.lens[G.first_slot + 64 + lane];
+    // full-matrix path (T < 2Q) skips column Tp: the last real column when T % 64 == 0
+    // (rust/src/algorithm/mod.rs:98,178); H(1,T) is handled by the host's re-run rule.
+    const uint32_t Elo = (Tlo < 2 * Q && Tlo > 0 && (Tlo & 63) == 0) ? Tlo - 1 : Tlo;
+    const uint32_t Ehi = (Thi < 2 * Q && Thi > 0 && (Thi & 63) == 0) ? Thi - 1 : Thi;
+    s2 best = {0, 0};
+    const uint32_t npass = (G.nstrips + W - 1) / W;
+
+    for (uint32_t pass = 0; pass < npass; pass++) {
+      const uint32_t strip = pass * W + wave;
+      const bool active = strip < G.nstrips;
+      uint32_t wlo = 0, whi = 0;
+      if (active) {
+        wlo = p.words[G.word_off + ((size_t)strip * 2 + 0) * 64 + lane];
+        whi = p.words[G.word_off + ((size_t)strip * 2 + 1) * 64 + lane];
+      }
+      s2 tabA[R], tabC[R], tabG[R], tabT[R], H[R];
+#pragma unroll
+      for (int r = 0; r < R; r++) {
+        const uint32_t col = strip * R + r;
+        const uint32_t clo = (wlo >> (2 * r)) & 3u, chi = (whi >> (2 * r)) & 3u;
+        const bool vlo = col < Elo, vhi = col < Ehi;
+        tabA[r] = s2{(vlo && clo == 0) ? mt : ms, (vhi && chi == 0) ? mt : ms};
+        tabC[r] = s2{(vlo && clo == 1) ? mt : ms, (vhi && chi == 1) ? mt : ms};
+        tabG[r] = s2{(vlo && clo == 2) ? mt : ms, (vhi && chi == 2) ? mt : ms};
+        tabT[r] = s2{(vlo && clo == 3) ? mt : ms, (vhi && chi == 3) ? mt : ms};
+        H[r] = s2{0, 0};
+      }
+      const uint32_t* gin = gb + (size_t)(pass & 1) * Qpad * 64;          // written by the previous pass
+      uint32_t* gout = gb + (size_t)((pass + 1) & 1) * Qpad * 64;
+      const bool from_global = pass > 0;          // wave 0's left boundary
+      const bool to_global = pass + 1 < npass;    // last wave's right boundary
+      s2 diag_in = {0, 0};
+
+      // stage block 0 of the inter-pass boundary for wave 0 (every wave copies rows wave, wave+W, ..)
+      if (from_global) {
+        for (int i = wave; i < B; i += W)
+          lds[((0 * 2 + 0) * B + i) * 64 + lane] =
+              __hip_atomic_load(gin + (size_t)i * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+
+      for (uint32_t s = 0; s < nblk + W - 1; s++) {
+        // prefetch the next block of the inter-pass boundary (used by wave 0 in superstep s + 1)
+        uint32_t pre[(B + W - 1) / W];
+        const bool do_pre = from_global && (s + 1 < nblk);
+        if (do_pre) {
+#pragma unroll
+          for (int i = 0; i < (B + W - 1) / W; i++) {
+            const int row = wave + i * W;
+            if (row < B)
+              pre[i] = __hip_atomic_load(gin + ((size_t)(s + 1) * B + row) * 64 + lane, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        const int blk = (int)s - wave;
+        if (active && blk >= 0 && (uint32_t)blk < nblk) {
+          const uint32_t qw = p.qwords[blk];
+          const uint32_t* in = lds + ((wave * 2 + (blk & 1)) * B) * 64 + lane;
+          uint32_t* out = lds + (((wave + 1) * 2 + (blk & 1)) * B) * 64 + lane;
+          const bool has_in = (wave > 0) || from_global;
+          const bool lds_out = wave + 1 < W;
+          const uint32_t x0 = (uint32_t)blk * B;
+          const int nrows = (Q - x0) < (uint32_t)B ? (int)(Q - x0) : B;
+          s2 left_next = has_in ? as_s2(in[0]) : s2{0, 0};
+#pragma unroll 1
+          for (int i = 0; i < nrows; i++) {
+            const s2 left_in = left_next;
+            if (has_in && i + 1 < nrows) left_next = as_s2(in[(i + 1) * 64]);
+            const uint32_t code = (qw >> (2 * i)) & 3u;
+            switch (code) {
+              // the trailing asm comments differ per case so that the optimiser cannot merge the four
+              // bodies into one with 16 operand selects
+              case 0: sw_row(H, tabA, best, left_in, diag_in, gapabs); asm volatile("; row A"); break;
+              case 1: sw_row(H, tabC, best, left_in, diag_in, gapabs); asm volatile("; row C"); break;
+              case 2: sw_row(H, tabG, best, left_in, diag_in, gapabs); asm volatile("; row G"); break;
+              default: sw_row(H, tabT, best, left_in, diag_in, gapabs); asm volatile("; row T"); break;
+            }
+            diag_in = left_in;
+            if (lds_out)
+              out[i * 64] = as_u32(H[R - 1]);
+            else if (to_global)
+              gout[((size_t)x0 + i) * 64 + lane] = as_u32(H[R - 1]);
+          }
+        }
+        if (do_pre) {
+#pragma unroll
+          for (int i = 0; i < (B + W - 1) / W; i++) {
+            const int row = wave + i * W;
+            if (row < B) lds[((0 * 2 + ((s + 1) & 1)) * B + row) * 64 + lane] = pre[i];
+          }
+        }
+        __syncthreads();
+      }
+      // the running maximum skipped the odd columns of the last row
+#pragma unroll
+      for (int r = 1; r < R; r += 2) best = pk_max(best, H[r]);
+    }
+    // reduce the W waves' maxima (each wave covered different columns of the same 128 targets)
+    lds[wave * 64 + lane] = as_u32(best);
+    __syncthreads();
+    if (wave == 0) {
+      s2 b = best;
+      for (int w = 1; w < W; w++) b = pk_max(b, as_s2(lds[w * 64 + lane]));
+      p.slot_scores[G.first_slot + lane] = (int)b.x;
+      p.slot_scores[G.first_slot + 64 + lane] = (int)b.y;
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int kW = 16;
+
+}  // namespace
+
+int score_waves_per_group() { return kW; }
+
+hipError_t launch_score(const ScoreParams& p, int n_workgroups, hipStream_t stream) {
+  if (p.n_groups == 0 || n_workgroups <= 0) return hipSuccess;
+  hipLaunchKernelGGL(sw_score_kernel<kW>, dim3(n_workgroups), dim3(kW * 64), 0, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace swhip

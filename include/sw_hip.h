@@ -1,0 +1,114 @@
+/*
+ * include/sw_hip.h -- ADDITIVE entry points of libsw_hip.so.
+ *
+ * The reference's C ABI is one pair per call (rust/src/bindings.rs:71-157,187-229) and cannot express a
+ * batch, a resident database, top-k or a score above 65535.  These symbols have no
+ * counterpart in rust/src/bindings.rs; each one cites the reference code whose job it takes over.  The
+ * five drop-in symbols of include/sw.h stay and give reference-identical answers for one pair.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success or a negative
+ * SW_E_* code and records a message readable with sw_hip_last_error(); nothing aborts or throws.
+ */
+#ifndef DLSA_AMD_SW_HIP_H
+#define DLSA_AMD_SW_HIP_H
+
+#include "sw.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SW_OK 0
+#define SW_E_NOGPU -1    /* no usable HIP device / kernels missing: there is NO CPU fallback */
+#define SW_E_ARG -2      /* bad argument (NULL pointer, invalid UTF-8, out-of-range size) */
+#define SW_E_HIP -3      /* a HIP runtime call failed */
+#define SW_E_NOMEM -4
+#define SW_E_DOMAIN -5   /* scoring outside the supported domain for this entry point */
+
+/* which reference entry point's semantics to reproduce */
+#define SW_PATH_LOW_MEMORY 0 /* rust/src/algorithm/mod.rs:204-445 incl. the T < 2Q dispatch at :213 */
+#define SW_PATH_SIMD 1       /* rust/src/lib.rs:105-136 */
+#define SW_PATH_STRAIGHT 2   /* rust/src/lib.rs:45-71 */
+
+/* ---- lifecycle ------------------------------------------------------------------------------------ */
+/* Selects the HIP device for the calling process (one process per GPU) and creates the library's
+ * stream.  Optional: every entry point initialises device 0 lazily.  Plays the role of "the Rust crate
+ * is stateless" (bindings.rs has no init) for a library that owns device state. */
+int sw_hip_init(int device);
+/* Thread-local message of the last failure on this thread ("" if none). */
+const char *sw_hip_last_error(void);
+/* Library/version string, the analogue of rust/src/lib.rs:214-216 get_version(). */
+const char *sw_hip_version(void);
+
+/* ---- wide score ----------------------------------------------------------------------------------- */
+/* The un-truncated int32 score of a Result returned by this library (struct Result carries 16 bits,
+ * rust/header/sw.h:8).  Equal to (int16_t)result->score on the reference's i16-safe domain. */
+int32_t sw_result_score32(const struct Result *result);
+
+/* ---- batch of independent pairs: what internal/worker/worker_impl.go:108-168 (ExecuteWork) does with
+ * one cgo call per pair.  out[i] receives what find_alignment_low_memory / _simd / _sequential_straight
+ * (per `path`) would return for (queries[i], targets[i]); free each with free_alignment_result().  All
+ * pairs run on the GPU in one submission. */
+int sw_align_batch(const char *const *queries, const char *const *targets, size_t n_pairs,
+                   struct AlignmentScores scores, int path, struct Result **out);
+
+/* ---- resident target database + top-k: what cli/__main__.py:153-173 computes client-side after every
+ * pair's result has travelled worker -> master -> CLI. */
+typedef struct sw_db sw_db;
+
+/* Builds a database from n sequences stored back to back in `flat`; sequence i is
+ * flat[offsets[i] .. offsets[i+1]) (offsets has n+1 entries).  Sequences are length-sorted, 2-bit
+ * packed in groups of 128 (DESIGN.md "Data layout") and uploaded; sequences with symbols outside
+ * ACGT are kept as bytes and scored by the exact kernel.  Returns NULL on failure. */
+sw_db *sw_db_create(const char *flat, const uint64_t *offsets, uint64_t n);
+/* Parses a FASTA file the way cli/__main__.py:19-34 does (id = first token after '>', multi-line
+ * bodies concatenated). */
+sw_db *sw_db_load_fasta(const char *path);
+void sw_db_free(sw_db *db);
+uint64_t sw_db_size(const sw_db *db);
+/* total residues */
+uint64_t sw_db_residues(const sw_db *db);
+
+/* One reported hit.  Ordering of hits: score descending, then target index ascending (the reference's
+ * order among equal scores is the master's arrival order, cli/__main__.py:171 + SURVEY.md A10, i.e. not
+ * deterministic; this is the declared replacement). */
+struct sw_hit {
+  uint64_t target_index;  /* index into the database as passed to sw_db_create */
+  int32_t score;          /* un-truncated */
+  uint32_t length;        /* strlen(query_aln) -- the worker's AlignmentDetail.Length, worker_impl.go:147 */
+  uint64_t max_x, max_y;  /* as struct Result */
+  char *query_aln;        /* free with free_c_string */
+  char *target_aln;
+};
+
+/* Scores `query` against every database sequence with find_alignment_low_memory semantics and returns
+ * the k best hits with full alignments.  *n_hits <= k.  Exact for every reported field. */
+int sw_db_search_topk(sw_db *db, const char *query, struct AlignmentScores scores, int k,
+                      struct sw_hit *hits, int *n_hits);
+/* Same, additionally restricted to targets in [first, first+count) -- the shard a rank owns when the
+ * database is split by target across GPUs. */
+/* All scores (int32, database order), for tests and for schedulers that want every pair. */
+int sw_db_scores(sw_db *db, const char *query, struct AlignmentScores scores, int32_t *scores_out);
+void sw_hits_free(struct sw_hit *hits, int n_hits);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------------------------------- */
+struct sw_kernel_stats {
+  double score_kernel_ms;   /* HIP-event time of the last inter-task score-kernel launch(es), on the
+                               library's stream */
+  double exact_kernel_ms;   /* same for the exact (intra-task) kernels + traceback walker */
+  uint64_t score_cells;     /* sum Q*T (unpadded) the score kernel covered */
+  uint64_t exact_cells;
+  uint32_t score_launches;
+  uint32_t rerun_pairs;     /* pairs re-run by the exact kernel (saturation / quirk / non-ACGT) */
+};
+int sw_hip_last_stats(struct sw_kernel_stats *out);
+
+/* The worker's capacity benchmark (internal/worker/worker_rust_benchmark.go:38-68, consumed by
+ * master/api_models/worker.py:7-16): cells per second of the batch path on synthetic DNA, as a
+ * float32-representable INTEGER-valued number (the master's field is a pydantic int). */
+float sw_hip_benchmark_cups(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLSA_AMD_SW_HIP_H */

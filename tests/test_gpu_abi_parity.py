@@ -1,0 +1,181 @@
+"""GPU parity of the drop-in C ABI (include/sw.h) against the oracle: every known-answer vector of the
+reference, random pairs on all three entry points (bit-exact strings, score, max_x, max_y), the quirk
+inputs, ownership rules.  Everything goes through the C ABI via dlsa_amd.bridge (ctypes)."""
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCORES = [(-1, 2, -1), (-1, 3, -1), (-3, 5, -2), (-2, 1, -1), (-1, 1, -1), (-2, 3, -3), (-5, 4, -1)]
+ENTRY = {"lowmem": "find_rust_alignment_simd_low_mem", "simd": "find_rust_alignment_simd",
+         "straight": "find_rust_alignment_sequential"}
+
+
+def _gpu(func, q, t, sc):
+    import dlsa_amd
+    gap, match, miss = sc
+    res, err = getattr(dlsa_amd, ENTRY[func])(q, t, dlsa_amd.AlignmentScore(match, miss, gap))
+    assert err is None, err
+    return res
+
+
+def _check(oracle, func, q, t, sc):
+    exp = oracle.align(func, q, t, *sc)
+    got = _gpu(func, q, t, sc)
+    assert exp is not None
+    assert (got.query, got.target, got.score, got.max_x, got.max_y) == (
+        exp["q"], exp["t"], exp["score"] & 0xFFFF, exp["max_x"], exp["max_y"]), (func, q, t, sc)
+
+
+def _rnd(rng, n, alpha="ACGT"):
+    return "".join(rng.choice(alpha) for _ in range(n))
+
+
+def test_known_answer_vectors(oracle, kat):
+    for v in kat["rust_lib_rs"]:
+        s = v["scores"]
+        sc = (s["gap"], s["match"], s["miss"])
+        for func in ENTRY:
+            got = _gpu(func, v["query"], v["target"], sc)
+            assert (got.query, got.target) == (v["q_aln"], v["t_aln"]), (func, v["id"])
+            _check(oracle, func, v["query"], v["target"], sc)
+    for v in kat["master_tests_data"]:
+        s = v["scores"]
+        got = _gpu("lowmem", v["query"], v["target"], (s["gap"], s["match"], s["miss"]))
+        assert (got.query, got.target, got.score, got.max_x, got.max_y) == (
+            v["q_aln"], v["t_aln"], v["score"], v["max_x"], v["max_y"])
+
+
+def test_fallback_chain_like_the_go_worker(oracle, kat):
+    import dlsa_amd
+    for v in kat["rust_lib_rs"][:12]:
+        s = v["scores"]
+        res, err = dlsa_amd.find_alignment_with_fallback(v["query"], v["target"],
+                                                         dlsa_amd.AlignmentScore(s["match"], s["miss"], s["gap"]))
+        assert err is None and (res.query, res.target) == (v["q_aln"], v["t_aln"])
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_random_pairs_all_entries(oracle, seed):
+    rng = random.Random(seed)
+    for _ in range(120):
+        mode = rng.random()
+        alpha = rng.choice(["AC", "ACGT", "ACGT", "A"])
+        if mode < 0.3:
+            Q, T = rng.randint(0, 40), rng.randint(0, 100)
+        elif mode < 0.5:  # ring path with T < Qp
+            Q = rng.randint(1, 31)
+            T = rng.randint(2 * Q, 70)
+        elif mode < 0.75:  # full path incl. T % 64 == 0
+            Q = rng.randint(30, 600)
+            T = rng.choice([64, 128, 192, 256, 320, rng.randint(1, 700)])
+        else:  # ring path, several strips / wrap
+            Q = rng.randint(1, 300)
+            T = rng.randint(2 * Q, 2 * Q + 900)
+        q, t = _rnd(rng, Q, alpha), _rnd(rng, T, alpha)
+        if rng.random() < 0.4 and Q > 3 and T > Q:
+            p = rng.randint(0, T - 1)
+            t = (t[:p] + q[:rng.randint(1, Q)] + t[p:])[:T]
+        sc = rng.choice(SCORES)
+        for func in ENTRY:
+            _check(oracle, func, q, t, sc)
+
+
+def test_quirk_inputs(oracle):
+    q = "G" * 80 + "TTTTTTTTTACGTA"
+    t = "C" * 59 + "ACGTA"
+    _check(oracle, "simd", q, t, (-1, 2, -1))
+    _check(oracle, "lowmem", q, t, (-1, 2, -1))
+    t2 = "C" * 63 + "A"
+    _check(oracle, "simd", "A" + "G" * 20, t2, (-1, 2, -1))   # H(1,T) is the only hit
+    _check(oracle, "simd", "A" + "G" * 80, t2, (-1, 2, -1))   # ... and is not computed when Tp < Qp
+    _check(oracle, "lowmem", "A" + "G" * 20, t2, (-1, 2, -1))
+    for func in ENTRY:  # no hit / empty inputs
+        for q, t in (("AAAA", "TTTT"), ("", "ACGT"), ("ACGT", ""), ("", "")):
+            _check(oracle, func, q, t, (-1, 2, -1))
+
+
+def test_longer_pairs_many_strips(oracle):
+    rng = random.Random(7)
+    q = _rnd(rng, 1500)
+    core = q[200:1300]
+    mutated = "".join(c if rng.random() > 0.08 else rng.choice("ACGT") for c in core)
+    t = _rnd(rng, 700) + mutated + _rnd(rng, 500)
+    for func in ENTRY:
+        _check(oracle, func, q, t, (-1, 2, -1))
+    t_long = _rnd(rng, 5000) + q[300:900] + _rnd(rng, 3000)   # ring path, T >> data_store_height
+    _check(oracle, "lowmem", q[300:1000], t_long, (-1, 2, -1))
+    _check(oracle, "lowmem", q, q, (-1, 2, -1))               # identical sequences
+
+
+def test_non_ascii_and_arbitrary_alphabet(oracle):
+    _check(oracle, "lowmem", "xxabcxx", "zzzzzabczzzzzzzzzzzz", (-1, 2, -1))
+    _check(oracle, "simd", "héllo wörld", "say héllo wörld now", (-1, 2, -1))
+    _check(oracle, "lowmem", "中文", "abc中文def", (-1, 2, -1))
+
+
+def test_invalid_utf8_and_gap_zero_return_null():
+    import dlsa_amd
+    from dlsa_amd import bridge
+    L = bridge.lib()
+    sc = dlsa_amd.AlignmentScore(2, -1, -1).c()
+    assert not L.find_alignment_low_memory(b"\xff\xfe", b"ACGT", sc)
+    assert not L.find_alignment_simd(b"ACGT", b"\xc3", sc)
+    # rust/src/algorithm/mod.rs:236-238: gap == 0 divides by zero on the ring path -> NULL, simd still works
+    z = dlsa_amd.AlignmentScore(2, -1, 0)
+    res, err = dlsa_amd.find_rust_alignment_simd_low_mem("AC", "ACGTACGT", z)
+    assert res is None and err is not None
+    res, err = dlsa_amd.find_alignment_with_fallback("AC", "ACGTACGT", z)
+    assert err is None
+    assert not L.find_alignment_parallel(b"A", b"A", 4, sc)
+    assert not L.find_alignment_sequential(b"A", b"A", sc)
+
+
+def test_ownership_rules():
+    import ctypes as C
+    import dlsa_amd
+    from dlsa_amd import bridge
+    L = bridge.lib()
+    sc = dlsa_amd.AlignmentScore(2, -1, -1).c()
+    L.free_alignment_result(None)
+    L.free_c_string(None)
+    r = L.find_alignment_low_memory(b"ACGT", b"ACGT", sc)
+    assert C.string_at(r.contents.query_ptr) == b"ACGT"
+    L.free_c_string(r.contents.query_ptr)      # either string may be freed first ...
+    L.free_alignment_result(r)                 # ... and the struct afterwards, exactly once
+    r = L.find_alignment_simd(b"ACGT", b"ACGT", sc)
+    L.free_c_string(r.contents.target_ptr)
+    L.free_c_string(r.contents.query_ptr)
+    L.free_alignment_result(r)
+
+
+def test_concurrent_callers(oracle):
+    # the Go worker enters from NumCPU-1 OS threads (worker_impl.go:204-238)
+    import threading
+    rng = random.Random(3)
+    pairs = [(_rnd(rng, rng.randint(5, 120)), _rnd(rng, rng.randint(5, 400))) for _ in range(64)]
+    exp = [oracle.align("lowmem", q, t, -1, 2, -1) for q, t in pairs]
+    got = [None] * len(pairs)
+
+    def work(k):
+        for i in range(k, len(pairs), 8):
+            got[i] = _gpu("lowmem", pairs[i][0], pairs[i][1], (-1, 2, -1))
+    th = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for e, g in zip(exp, got):
+        assert (g.query, g.target, g.score, g.max_x, g.max_y) == (e["q"], e["t"], e["score"], e["max_x"], e["max_y"])
+
+
+def test_align_batch_matches_single_calls(oracle):
+    import dlsa_amd
+    from dlsa_amd import bridge
+    rng = random.Random(9)
+    qs = [_rnd(rng, rng.randint(0, 300)) for _ in range(200)]
+    ts = [_rnd(rng, rng.randint(0, 600)) for _ in range(200)]
+    for path, func in ((0, "lowmem"), (1, "simd"), (2, "straight")):
+        res = bridge.align_batch(qs, ts, dlsa_amd.AlignmentScore(2, -1, -1), path)
+        for q, t, g in zip(qs, ts, res):
+            e = oracle.align(func, q, t, -1, 2, -1)
+            assert (g.query, g.target, g.score, g.max_x, g.max_y) == (e["q"], e["t"], e["score"], e["max_x"], e["max_y"])

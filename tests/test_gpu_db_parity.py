@@ -1,0 +1,125 @@
+"""GPU parity of the database path (include/sw_hip.h: sw_db_create / sw_db_scores / sw_db_search_topk):
+the inter-task packed-int16 score kernel + re-run rules + top-k + exact alignments, against the oracle's
+find_alignment_low_memory restatement on the same seeded inputs."""
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rnd(rng, n, alpha="ACGT"):
+    return "".join(rng.choice(alpha) for _ in range(n))
+
+
+def _oracle_all(oracle, q, targets, sc):
+    return [oracle.align("lowmem", q, t, *sc) for t in targets]
+
+
+def _topk(exp, k):
+    order = sorted(range(len(exp)), key=lambda i: (-exp[i]["score"], i))[:k]
+    return order
+
+
+def _run(oracle, q, targets, sc, k=5):
+    import dlsa_amd
+    from dlsa_amd import bridge
+    gap, match, miss = sc
+    s = dlsa_amd.AlignmentScore(match, miss, gap)
+    db = bridge.Database(seqs=targets)
+    try:
+        exp = _oracle_all(oracle, q, targets, sc)
+        got = db.scores(q, s)
+        bad = [(i, int(got[i]), exp[i]["score"], len(targets[i])) for i in range(len(targets)) if int(got[i]) != exp[i]["score"]]
+        assert not bad, bad[:10]
+        hits = db.search_topk(q, s, k)
+        order = _topk(exp, k)
+        assert [h["target_index"] for h in hits] == order
+        for h, i in zip(hits, order):
+            e = exp[i]
+            assert (h["score"], h["max_x"], h["max_y"], h["query_aln"], h["target_aln"], h["length"]) == (
+                e["score"], e["max_x"], e["max_y"], e["q"], e["t"], len(e["q"]))
+    finally:
+        db.close()
+
+
+def test_small_db_single_pass(oracle):
+    rng = random.Random(1)
+    q = _rnd(rng, 300)
+    targets = [_rnd(rng, rng.randint(1, 250)) for _ in range(300)]
+    targets[17] = targets[17][:40] + q[100:220] + targets[17][40:60]
+    _run(oracle, q, targets, (-1, 2, -1))
+
+
+def test_multi_pass_and_length_skew(oracle):
+    rng = random.Random(2)
+    q = _rnd(rng, 520)
+    targets = [_rnd(rng, rng.randint(200, 1400)) for _ in range(200)]
+    for i in (3, 50, 77):
+        p = rng.randint(0, 100)
+        targets[i] = targets[i][:p] + q[rng.randint(0, 100):rng.randint(300, 520)] + targets[i][p:]
+    _run(oracle, q, targets, (-1, 2, -1))
+    _run(oracle, q, targets, (-3, 5, -2))
+
+
+def test_quirk_lengths_and_ring_targets(oracle):
+    rng = random.Random(3)
+    q = _rnd(rng, 100)
+    # T % 64 == 0 on the full path (T < 2Q), ring-path targets (T >= 2Q), empty and 1-residue targets
+    lens = [64, 128, 192, 63, 65, 127, 129, 199, 200, 201, 256, 320, 1, 0, 2, 500, 1000] * 8
+    targets = [_rnd(rng, n) for n in lens]
+    for i in range(0, len(targets), 5):
+        n = len(targets[i])
+        if n >= 20:
+            targets[i] = targets[i][:n - 15] + q[40:55]      # a hit that ends on the last column
+    _run(oracle, q, targets, (-1, 2, -1))
+    # short query: ring path with T < Qp (quirk Q2) and first-row-only hits
+    q2 = _rnd(rng, 20)
+    targets2 = [_rnd(rng, rng.randint(40, 63)) for _ in range(150)] + [q2[:1] * 64, "C" * 63 + q2[0]]
+    _run(oracle, q2, targets2, (-1, 2, -1))
+    q3 = "A" + _rnd(rng, 30, "CG")
+    targets3 = ["C" * 63 + "A", "G" * 127 + "A", "C" * 64, "A" * 64] + [_rnd(rng, 64, "CGT") for _ in range(40)]
+    _run(oracle, q3, targets3, (-1, 2, -1))
+
+
+def test_non_acgt_sequences_take_the_exact_path(oracle):
+    rng = random.Random(4)
+    q = _rnd(rng, 150)
+    targets = [_rnd(rng, rng.randint(50, 300)) for _ in range(140)]
+    targets[5] = targets[5][:20] + "NNNN" + q[10:90] + "acgt"
+    targets[9] = "xyz" * 30
+    _run(oracle, q, targets, (-1, 2, -1))
+    qn = q[:70] + "N" + q[70:]
+    _run(oracle, qn, targets, (-1, 2, -1))
+
+
+def test_int16_saturation_reruns_in_int32(oracle):
+    rng = random.Random(5)
+    core = _rnd(rng, 7000)
+    q = core
+    targets = [_rnd(rng, 300) for _ in range(130)]
+    targets[11] = _rnd(rng, 10) + core[100:6900] + _rnd(rng, 10)   # score 5 * 6800 = 34000 > 32767
+    import dlsa_amd
+    from dlsa_amd import bridge
+    s = dlsa_amd.AlignmentScore(5, -4, -4)
+    db = bridge.Database(seqs=targets)
+    try:
+        got = db.scores(q, s)
+        exp = oracle.clean_score_plain(q, targets[11], -4, 5, -4)   # int32 model: the i16 reference wraps here
+        assert exp >= 34000 and int(got[11]) == exp
+        for i in range(len(targets)):
+            if i != 11:
+                assert int(got[i]) == oracle.clean_score_plain(q, targets[i], -4, 5, -4)
+        hits = db.search_topk(q, s, 1)
+        assert hits[0]["target_index"] == 11 and hits[0]["score"] == exp and hits[0]["length"] >= 6800
+    finally:
+        db.close()
+
+
+def test_c1_shape_1kb_query_vs_1000_targets(oracle):
+    # BASELINE.json configs[0]: 1 query (1 kb) vs 1000 targets (~1 kb), match 2 / mismatch 1 / gap 1, top-k 5
+    rng = random.Random(6)
+    q = _rnd(rng, 1000)
+    targets = [_rnd(rng, rng.randint(900, 1100)) for _ in range(1000)]
+    targets[123] = targets[123][:300] + q[200:700] + targets[123][300:500]
+    _run(oracle, q, targets, (-1, 2, -1), k=5)
