@@ -66,17 +66,26 @@ struct ScoreGroup {       // one group of up to 128 length-sorted targets
   uint32_t first_slot;    // index of lane 0 / half 0 in the per-slot arrays (lens, order); 128 slots
 };
 
+struct ScoreUnit {        // one work unit: W*16 target columns of one group against the whole query
+  uint32_t group;
+  uint32_t pass;
+};
+
 struct ScoreParams {
   const uint32_t* words;      // packed residues, 2 bits each, 16 per dword
   const ScoreGroup* groups;   // n_groups
   const uint32_t* lens;       // per slot: target length (0 for padding slots)
   const uint32_t* qwords;     // query, 2 bits per residue, 16 per dword (row-block aligned)
   uint32_t Q;
-  uint32_t n_groups;
-  int32_t* slot_scores;       // per slot: best H over the effective domain (32767 = saturated)
-  uint32_t* gbound;           // per resident workgroup: 2 * Q_pad * 64 dwords of inter-pass boundary
-  uint64_t gbound_stride;     // dwords per workgroup
+  const ScoreUnit* units;     // n_units, ordered (group, pass)
+  uint32_t n_units;
+  int32_t* slot_scores;       // per slot: best H over the effective domain (32767 = saturated); zeroed
+  uint32_t* gbound;           // ring of inter-pass boundary columns: ring_slots * gbound_stride dwords
+  uint64_t gbound_stride;     // dwords per ring slot (Q_pad * 64)
+  uint32_t ring_slots;
+  uint32_t* prog;             // per unit: boundary blocks published / completion (zeroed before launch)
   uint32_t* ticket;           // work counter (zeroed before launch)
+  uint32_t* err;              // set to 1 if a dependency wait timed out (zeroed before launch)
   int match, miss, gap;
 };
 hipError_t launch_score(const ScoreParams& p, int n_workgroups, hipStream_t stream);

@@ -67,7 +67,7 @@ struct Context {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   DevBuf sym, pairs, outs, dirs, bnd, ops;            // exact path scratch
-  DevBuf qwords, slot_scores, gbound, ticket;          // score path scratch
+  DevBuf qwords, slot_scores, gbound, ticket, prog;    // score path scratch
   sw_kernel_stats stats{};
   size_t scratch_budget = (size_t)8 << 30;
 };
@@ -548,6 +548,8 @@ struct sw_db {
   uint32_t* d_words = nullptr;
   uint32_t* d_lens = nullptr;
   ScoreGroup* d_groups = nullptr;
+  ScoreUnit* d_units = nullptr;
+  uint32_t n_units = 0;
   std::vector<uint32_t> generic;  // targets scored by the exact kernel only
   uint32_t max_len = 0;
 };
@@ -569,6 +571,7 @@ void db_release(sw_db* db) {
   if (db->d_words) (void)hipFree(db->d_words);
   if (db->d_lens) (void)hipFree(db->d_lens);
   if (db->d_groups) (void)hipFree(db->d_groups);
+  if (db->d_units) (void)hipFree(db->d_units);
   delete db;
 }
 
@@ -649,7 +652,20 @@ sw_db* db_build(std::string&& flat, std::vector<uint64_t>&& off) {
       }
     }
   }
+  std::vector<ScoreUnit> units;
+  {
+    const uint32_t W = (uint32_t)score_waves_per_group();
+    for (size_t g = 0; g < ngroups; g++)
+      for (uint32_t pass = 0; pass * W < db->groups[g].nstrips; pass++) units.push_back(ScoreUnit{(uint32_t)g, pass});
+    db->n_units = (uint32_t)units.size();
+  }
   if (ngroups) {
+    if (hipMalloc(&db->d_units, std::max<size_t>(units.size(), 1) * sizeof(ScoreUnit)) != hipSuccess ||
+        hipMemcpy(db->d_units, units.data(), units.size() * sizeof(ScoreUnit), hipMemcpyHostToDevice) != hipSuccess) {
+      db_release(db);
+      fail(SW_E_NOMEM, "hipMalloc failed for the database");
+      return nullptr;
+    }
     if (hipMalloc(&db->d_words, words.size() * 4) != hipSuccess || hipMalloc(&db->d_lens, lens.size() * 4) != hipSuccess ||
         hipMalloc(&db->d_groups, ngroups * sizeof(ScoreGroup)) != hipSuccess) {
       db_release(db);
@@ -691,28 +707,34 @@ int db_scores_locked(sw_db* db, const QueryPrep& qp, Scoring sc, std::vector<int
   } else {
     const uint32_t nblk = (Q + kScoreB - 1) / kScoreB;
     const size_t Qpad = (size_t)nblk * kScoreB;
-    const int W = score_waves_per_group();
-    const int per_cu = std::max(1, 16 / W);
-    const int nwg = (int)std::min<size_t>(db->groups.size(), (size_t)c.cus * per_cu);
-    const size_t gb_stride = 2 * Qpad * 64;
+    const int nwg = (int)std::min<size_t>(db->n_units, (size_t)c.cus);
+    const uint32_t ring_slots = (uint32_t)std::max(2 * nwg, 2);
+    const size_t gb_stride = Qpad * 64;
     int rc;
     if ((rc = c.qwords.ensure(qp.qwords.size() * 4))) return rc;
     if ((rc = c.slot_scores.ensure(db->slot_target.size() * 4))) return rc;
-    if ((rc = c.gbound.ensure((size_t)nwg * gb_stride * 4))) return rc;
+    if ((rc = c.gbound.ensure((size_t)ring_slots * gb_stride * 4))) return rc;
     if ((rc = c.ticket.ensure(256))) return rc;
+    if ((rc = c.prog.ensure(std::max<size_t>(db->n_units * 4, 16)))) return rc;
     HIPCK(hipMemcpyAsync(c.qwords.p, qp.qwords.data(), qp.qwords.size() * 4, hipMemcpyHostToDevice, c.stream));
     HIPCK(hipMemsetAsync(c.ticket.p, 0, 256, c.stream));
+    HIPCK(hipMemsetAsync(c.prog.p, 0, std::max<size_t>(db->n_units * 4, 16), c.stream));
+    HIPCK(hipMemsetAsync(c.slot_scores.p, 0, db->slot_target.size() * 4, c.stream));
     ScoreParams p{};
     p.words = db->d_words;
     p.groups = db->d_groups;
     p.lens = db->d_lens;
     p.qwords = (const uint32_t*)c.qwords.p;
     p.Q = Q;
-    p.n_groups = (uint32_t)db->groups.size();
+    p.units = db->d_units;
+    p.n_units = db->n_units;
     p.slot_scores = (int32_t*)c.slot_scores.p;
     p.gbound = (uint32_t*)c.gbound.p;
     p.gbound_stride = gb_stride;
+    p.ring_slots = ring_slots;
+    p.prog = (uint32_t*)c.prog.p;
     p.ticket = (uint32_t*)c.ticket.p;
+    p.err = (uint32_t*)c.ticket.p + 32;
     p.match = sc.match;
     p.miss = sc.miss;
     p.gap = sc.gap;
@@ -721,7 +743,10 @@ int db_scores_locked(sw_db* db, const QueryPrep& qp, Scoring sc, std::vector<int
     HIPCK(hipEventRecord(c.ev1, c.stream));
     std::vector<int32_t> slot(db->slot_target.size());
     HIPCK(hipMemcpyAsync(slot.data(), c.slot_scores.p, slot.size() * 4, hipMemcpyDeviceToHost, c.stream));
+    uint32_t kerr = 0;
+    HIPCK(hipMemcpyAsync(&kerr, (uint32_t*)c.ticket.p + 32, 4, hipMemcpyDeviceToHost, c.stream));
     HIPCK(hipStreamSynchronize(c.stream));
+    if (kerr) return fail(SW_E_HIP, "score kernel: a pass-chain dependency wait timed out");
     float ms = 0;
     HIPCK(hipEventElapsedTime(&ms, c.ev0, c.ev1));
     c.stats.score_kernel_ms += ms;
