@@ -30,7 +30,9 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB,
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           # keep wave-uniform branches as real branches (see the row switch in sw_score.hip)
+           "-mllvm", "-structurizecfg-skip-uniform-regions=true", "-o", LIB,
            os.path.join(CSRC, "sw_exact.hip"), os.path.join(CSRC, "sw_score.hip"),
            "-x", "hip", os.path.join(CSRC, "sw_lib.cpp")]
     if verbose:

@@ -74,13 +74,13 @@ static double time_ms(F f, int reps) {
   CK(hipEventRecord(e0)); for (int i = 0; i < reps; i++) f(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / reps;
 }
-int main() {
+int main(int argc, char** argv) {
   hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
   printf("device %s CUs %d clock %d kHz wave %d\n", p.name, p.multiProcessorCount, p.clockRate, p.warpSize);
   int *in, *out; CK(hipMalloc(&in, 4096)); CK(hipMalloc(&out, 4 * 256 * 4096 * 4));
   std::vector<int> h(1024); for (int i = 0; i < 1024; i++) h[i] = (i * 2654435761u) & 0x7fff7fff; h[5] = 0x00010001;
   CK(hipMemcpy(in, h.data(), 4096, hipMemcpyHostToDevice));
-  const int iters = 20000;
+  const int iters = argc > 1 ? atoi(argv[1]) : 20000;
   const int cus = p.multiProcessorCount;
   for (int wps = 1; wps <= 8; wps *= 2) {           // waves per SIMD: blocks of 256 threads = 4 waves = 1 per SIMD
     int blocks = cus * wps;

@@ -49,21 +49,60 @@ __device__ __forceinline__ s2 as_s2(uint32_t v) { return __builtin_bit_cast(s2, 
 __device__ __forceinline__ uint32_t as_u32(s2 v) { return __builtin_bit_cast(uint32_t, v); }
 
 // One query row over the wave's R columns.  H[r] holds H(x-1, col r) on entry and H(x, col r) on exit.
+// Reference form (kept for documentation and as the source of truth for the asm below):
+//   hl = left_in; hd = diag_in;
+//   for r: hu = H[r]; m = max(hl, hu); if (r odd) best = max(best, m);
+//          t = sat_sub_u16(m, |gap|); d = sat_add_i16(hd, tab[r]); h = max(t, d); hd = hu; hl = h; H[r] = h;
+//
+// Hand-scheduled in blocks of four cells so that H[] is updated IN PLACE (the compiler's version copied
+// the 16 H registers back at the bottom of every row) with the next cell's diag + s computed one cell
+// ahead, before the old H value is overwritten.  gfx950 needs one wait state between a packed op and a
+// dependent packed op (hipcc pads `s_nop 0` itself but pads nothing inside asm): every dependent pair
+// below is separated by an independent instruction or an explicit s_nop.
+//   d  : in  = diag + s of the block's first cell, out = diag + s of the next block's first cell
+//   tn : tab of the cell after the block (any register for the last block; that result is unused)
+__device__ __forceinline__ void sw_cells4(s2& h0, s2& h1, s2& h2, s2& h3, s2 t1, s2 t2, s2 t3, s2 tn, s2 hl,
+                                          s2& d, s2& best, uint32_t gap2) {
+  s2 m, n, a;
+  asm volatile(
+      "v_pk_max_i16 %[m], %[hl], %[h0]\n\t"
+      "v_pk_add_i16 %[a], %[h0], %[t1] clamp\n\t"
+      "v_pk_sub_u16 %[m], %[m], %[g] clamp\n\t"
+      "s_nop 0\n\t"
+      "v_pk_max_i16 %[h0], %[m], %[d]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_max_i16 %[m], %[h0], %[h1]\n\t"
+      "v_pk_add_i16 %[d], %[h1], %[t2] clamp\n\t"
+      "v_pk_sub_u16 %[n], %[m], %[g] clamp\n\t"
+      "v_pk_max_i16 %[best], %[best], %[m]\n\t"
+      "v_pk_max_i16 %[h1], %[n], %[a]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_max_i16 %[m], %[h1], %[h2]\n\t"
+      "v_pk_add_i16 %[a], %[h2], %[t3] clamp\n\t"
+      "v_pk_sub_u16 %[m], %[m], %[g] clamp\n\t"
+      "s_nop 0\n\t"
+      "v_pk_max_i16 %[h2], %[m], %[d]\n\t"
+      "s_nop 0\n\t"
+      "v_pk_max_i16 %[m], %[h2], %[h3]\n\t"
+      "v_pk_add_i16 %[d], %[h3], %[tn] clamp\n\t"
+      "v_pk_sub_u16 %[n], %[m], %[g] clamp\n\t"
+      "v_pk_max_i16 %[best], %[best], %[m]\n\t"
+      "v_pk_max_i16 %[h3], %[n], %[a]\n\t"
+      "s_nop 0"
+      : [h0] "+v"(h0), [h1] "+v"(h1), [h2] "+v"(h2), [h3] "+v"(h3), [d] "+v"(d), [best] "+v"(best),
+        [m] "=&v"(m), [n] "=&v"(n), [a] "=&v"(a)
+      : [t1] "v"(t1), [t2] "v"(t2), [t3] "v"(t3), [tn] "v"(tn), [hl] "v"(hl), [g] "s"(gap2));
+}
+
 __device__ __forceinline__ void sw_row(s2 (&H)[R], const s2 (&tab)[R], s2& best, s2 left_in, s2 diag_in,
-                                       s2 gapabs) {
-  s2 hl = left_in, hd = diag_in;
+                                       uint32_t gap2) {
+  static_assert(R % 4 == 0, "the row is scheduled in blocks of four cells");
+  s2 d = pk_add_sat(diag_in, tab[0]);
+  sw_cells4(H[0], H[1], H[2], H[3], tab[1], tab[2], tab[3], tab[4], left_in, d, best, gap2);
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    const s2 hu = H[r];
-    const s2 m = pk_max(hl, hu);
-    if (r & 1) best = pk_max(best, m);
-    const s2 t = pk_subu_sat(m, gapabs);     // max(left, up) + gap, floored at 0
-    const s2 d = pk_add_sat(hd, tab[r]);     // diag + s, saturating at 32767
-    const s2 h = pk_max(t, d);               // >= 0 because t >= 0
-    hd = hu;
-    hl = h;
-    H[r] = h;
-  }
+  for (int r = 4; r < R; r += 4)
+    sw_cells4(H[r], H[r + 1], H[r + 2], H[r + 3], tab[r + 1], tab[r + 2], tab[r + 3], tab[r + 4 < R ? r + 4 : r + 3],
+              H[r - 1], d, best, gap2);
 }
 
 // Bounded spin on a progress counter written by another workgroup (sc1 load = L1 bypass).  A counter that
@@ -84,7 +123,7 @@ __global__ void __launch_bounds__(W * 64) sw_score_kernel(ScoreParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const uint32_t Q = p.Q;
   const uint32_t nblk = (Q + B - 1) / B;
-  const s2 gapabs = {(short)(-p.gap), (short)(-p.gap)};
+  const uint32_t gapabs = __builtin_amdgcn_readfirstlane(((uint32_t)(-p.gap) & 0xffffu) * 0x10001u);
   const short mt = (short)p.match, ms = (short)p.miss;
   constexpr uint32_t PUB = 8;  // blocks per publication of the inter-pass boundary
 
@@ -180,8 +219,11 @@ __global__ void __launch_bounds__(W * 64) sw_score_kernel(ScoreParams p) {
           if (has_in && i + 1 < nrows) left_next = as_s2(in[(i + 1) * 64]);
           const uint32_t code = (qw >> (2 * i)) & 3u;
           switch (code) {
-            // the trailing asm comments differ per case so that the optimiser cannot merge the four
-            // bodies into one with 16 operand selects
+            // Four bodies, one per query nucleotide, selected by a scalar branch.  The trailing asm comments
+            // differ per case so that the optimiser cannot merge the bodies; the library is built with
+            // -mllvm -structurizecfg-skip-uniform-regions=true so that this uniform switch stays a real
+            // branch (structurised, old and new H would both be live across the sibling bodies and every
+            // row would pay 16-32 register copies).
             case 0: sw_row(H, tabA, best, left_in, diag_in, gapabs); asm volatile("; row A"); break;
             case 1: sw_row(H, tabC, best, left_in, diag_in, gapabs); asm volatile("; row C"); break;
             case 2: sw_row(H, tabG, best, left_in, diag_in, gapabs); asm volatile("; row G"); break;
