@@ -1,0 +1,133 @@
+#!/usr/bin/env python3
+"""Generates dlsa_amd/csrc/sw_score_asm.inc: the hand-scheduled gfx950 row loop of the inter-task score
+kernel (sw_score.hip) as one inline-asm string.
+
+Why generated asm: the loop body exists in 8 variants (4 query nucleotides x 2 row parities) that must all
+update the 16 H registers IN PLACE and read 64 table registers; hipcc's register allocator inserted 16-32
+register copies per row around any C++ / per-cell inline-asm formulation (see DESIGN.md "Score kernel").
+Here every register is named explicitly:
+
+  v48..v63    H[0..15]            (pinned in/out operands of the asm statement, 4 tuples of 4)
+  v64..v79    tabA[0..15]   v80..v95 tabC   v96..v111 tabG   v112..v127 tabT   (pinned inputs)
+  v40 m  v41 n  v42 a  v43 d  v44 L1  v45 D1  v46 L0  v47 D0     (clobbered temporaries)
+
+Per cell (see sw_score.hip for the recurrence): v_pk_max_i16, v_pk_sub_u16 clamp, v_pk_add_i16 clamp (the
+NEXT cell's diag + s, computed before the old H is overwritten), v_pk_max_i16, and on odd columns the running
+maximum.  gfx950 needs one wait state between a packed op and a dependent packed op; every such pair is
+separated by an independent instruction or an s_nop.
+
+Row loop, unrolled by two so that the left/diag values alternate between (L0, D0) and (L1, D1) without moves:
+the left neighbour's column arrives through LDS at [addr + 256 * row]; the value a row needs as `left` is also
+the next row's `diag`, and is simply read twice.
+"""
+import os
+
+H0, TAB0 = 48, 64
+M, N, A, D, L1, D1, L0, D0 = 40, 41, 42, 43, 44, 45, 46, 47
+
+
+def h(r):
+    return f"v{H0 + r}"
+
+
+def tab(code, r):
+    return f"v{TAB0 + 16 * code + r}"
+
+
+def cells4(code, r0, hl):
+    """four cells r0..r0+3; d (v43) holds diag+s of cell r0 on entry and of cell r0+4 on exit"""
+    t = lambda r: tab(code, min(r, 15))
+    h0, h1, h2, h3 = h(r0), h(r0 + 1), h(r0 + 2), h(r0 + 3)
+    m, n, a, d = f"v{M}", f"v{N}", f"v{A}", f"v{D}"
+    return [
+        f"v_pk_max_i16 {m}, {hl}, {h0}",
+        f"v_pk_add_i16 {a}, {h0}, {t(r0 + 1)} clamp",
+        f"v_pk_sub_u16 {m}, {m}, %[g] clamp",
+        "s_nop 0",
+        f"v_pk_max_i16 {h0}, {m}, {d}",
+        "s_nop 0",
+        f"v_pk_max_i16 {m}, {h0}, {h1}",
+        f"v_pk_add_i16 {d}, {h1}, {t(r0 + 2)} clamp",
+        f"v_pk_sub_u16 {n}, {m}, %[g] clamp",
+        f"v_pk_max_i16 %[best], %[best], {m}",
+        f"v_pk_max_i16 {h1}, {n}, {a}",
+        "s_nop 0",
+        f"v_pk_max_i16 {m}, {h1}, {h2}",
+        f"v_pk_add_i16 {a}, {h2}, {t(r0 + 3)} clamp",
+        f"v_pk_sub_u16 {m}, {m}, %[g] clamp",
+        "s_nop 0",
+        f"v_pk_max_i16 {h2}, {m}, {d}",
+        "s_nop 0",
+        f"v_pk_max_i16 {m}, {h2}, {h3}",
+    ] + ([f"v_pk_add_i16 {d}, {h3}, {t(r0 + 4)} clamp"] if r0 + 4 < 16 else ["s_nop 0"]) + [
+        f"v_pk_sub_u16 {n}, {m}, %[g] clamp",
+        f"v_pk_max_i16 %[best], %[best], {m}",
+        f"v_pk_max_i16 {h3}, {n}, {a}",
+        "s_nop 0",
+    ]
+
+
+def body(code, parity):
+    left, diag = (f"v{L0}", f"v{D0}") if parity == 0 else (f"v{L1}", f"v{D1}")
+    out = [f"v_pk_add_i16 v{D}, {diag}, {tab(code, 0)} clamp"]
+    out += cells4(code, 0, left)
+    for r0 in (4, 8, 12):
+        out += cells4(code, r0, h(r0 - 1))
+    return out
+
+
+def row(parity, wstride):
+    p = "e" if parity == 0 else "o"
+    nl, nd = (L1, D1) if parity == 0 else (L0, D0)
+    off = 256 * parity
+    o = ["s_waitcnt lgkmcnt(0)",
+         f"ds_read_b32 v{nl}, %[addr] offset:{off + 256}",   # next row's left
+         f"ds_read_b32 v{nd}, %[addr] offset:{off}",         # this row's left = next row's diag
+         "s_bitcmp1_b32 %[qw], 1", f"s_cbranch_scc1 Lhi_{p}_%=",
+         "s_bitcmp1_b32 %[qw], 0", f"s_cbranch_scc1 LC_{p}_%="]
+    o += body(0, parity) + [f"s_branch Ljoin_{p}_%=", f"LC_{p}_%=:"]
+    o += body(1, parity) + [f"s_branch Ljoin_{p}_%=", f"Lhi_{p}_%=:",
+                            "s_bitcmp1_b32 %[qw], 0", f"s_cbranch_scc1 LT_{p}_%="]
+    o += body(2, parity) + [f"s_branch Ljoin_{p}_%=", f"LT_{p}_%=:"]
+    o += body(3, parity) + [f"Ljoin_{p}_%=:", "s_lshr_b32 %[qw], %[qw], 2",
+                            "s_bitcmp1_b32 %[n], 8", f"s_cbranch_scc0 Lnl_{p}_%=",
+                            f"ds_write_b32 %[addr], {h(15)} offset:{wstride + off}", f"Lnl_{p}_%=:",
+                            "s_bitcmp1_b32 %[n], 9", f"s_cbranch_scc0 Lng_{p}_%=",
+                            f"global_store_dword %[goff], {h(15)}, %[gb] sc1",
+                            "v_add_u32_e32 %[goff], 0x100, %[goff]", f"Lng_{p}_%=:"]
+    return o
+
+
+def generate(wstride):
+    o = [f"v_mov_b32_e32 v{D0}, %[diag]",
+         f"ds_read_b32 v{L0}, %[addr]",
+         "s_and_b32 %[i], %[n], 0xff",
+         "Ltop_%=:"]
+    o += row(0, wstride)
+    o += ["s_sub_u32 %[i], %[i], 1", "s_cmp_eq_u32 %[i], 0", "s_cbranch_scc1 Lexit_%="]
+    o += row(1, wstride)
+    o += ["v_add_u32_e32 %[addr], 0x200, %[addr]",
+          "s_sub_u32 %[i], %[i], 1", "s_cmp_lg_u32 %[i], 0", "s_cbranch_scc1 Ltop_%=",
+          "Lexit_%=:",
+          "s_waitcnt lgkmcnt(0)",   # the prefetches into L0/D0 have landed before the registers are released
+          f"v_mov_b32_e32 %[diag], v{D0}"]
+    return o
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    # ring geometry must match sw_score.hip: D slots x B rows x 256 bytes per wave
+    Dslots, B = 2, 16
+    lines = generate(Dslots * B * 256)
+    with open(os.path.join(here, "sw_score_asm.inc"), "w") as f:
+        f.write("// GENERATED by gen_score_asm.py -- do not edit.  Row loop of sw_score_kernel (gfx950).\n")
+        f.write(f"#define SW_SCORE_ASM_D {Dslots}\n#define SW_SCORE_ASM_B {B}\n")
+        f.write("#define SW_SCORE_ROWS_ASM \\\n")
+        for ln in lines:
+            f.write(f'  "{ln}\\n\\t" \\\n')
+        f.write('  ""\n')
+    print(len(lines), "asm lines")
+
+
+if __name__ == "__main__":
+    main()

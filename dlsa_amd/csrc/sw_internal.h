@@ -57,7 +57,7 @@ hipError_t launch_walk(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pa
 
 // ---- inter-task score kernel ---------------------------------------------------------------------------
 constexpr int kScoreR = 16;       // target columns per wave (one 2-bit packed dword per target)
-constexpr int kScoreB = 16;       // query rows per pipeline block (one 2-bit packed dword of the query)
+constexpr int kScoreB = 16;       // query rows per hand-over block (one 2-bit packed dword of the query)
 constexpr int kGroupTargets = 128; // 64 lanes x 2 packed int16 halves
 
 struct ScoreGroup {       // one group of up to 128 length-sorted targets
