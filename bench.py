@@ -61,12 +61,15 @@ def cpu_baseline(query, flat, offsets, n_pairs, threads):
 
 
 def main():
+    global Q_LEN, T_LEN
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--targets", type=int, default=N_TARGETS, help="targets per GPU (default = the named workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tlen", type=int, default=T_LEN, help="target length (default = the named workload)")
+    ap.add_argument("--qlen", type=int, default=Q_LEN, help="query length (default = the named workload)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -89,6 +92,7 @@ def main():
         raise SystemExit(f"sw_hip_init({local_rank}) failed: {bridge.last_error()}")
 
     n_targets = args.targets
+    Q_LEN, T_LEN = args.qlen, args.tlen
     # the query is the same on every rank; every rank owns its own shard of targets
     query = synth(np.random.default_rng(SEED), 1, Q_LEN)[0].tobytes()
     flat, offsets = synth(np.random.default_rng(SEED + 1 + rank), n_targets, T_LEN)

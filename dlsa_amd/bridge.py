@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libsw_hip.so")
+    # SW_HIP_LIB: load another build of the same library (experiments); default is the in-tree build
+    return os.environ.get("SW_HIP_LIB") or os.path.join(_HERE, "lib", "libsw_hip.so")
 
 
 class SwHipError(RuntimeError):

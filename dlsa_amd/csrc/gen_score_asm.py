@@ -21,6 +21,7 @@ the left neighbour's column arrives through LDS at [addr + 256 * row]; the value
 the next row's `diag`, and is simply read twice.
 """
 import os
+import sys
 
 H0, TAB0 = 48, 64
 M, N, A, D, L1, D1, L0, D0 = 40, 41, 42, 43, 44, 45, 46, 47
@@ -67,6 +68,9 @@ def cells4(code, r0, hl):
     ]
 
 
+NO_NOPS = "--no-nops" in sys.argv  # timing experiment only: results are WRONG without the wait states
+
+
 def body(code, parity):
     left, diag = (f"v{L0}", f"v{D0}") if parity == 0 else (f"v{L1}", f"v{D1}")
     out = [f"v_pk_add_i16 v{D}, {diag}, {tab(code, 0)} clamp"]
@@ -80,9 +84,13 @@ def row(parity, wstride):
     p = "e" if parity == 0 else "o"
     nl, nd = (L1, D1) if parity == 0 else (L0, D0)
     off = 256 * parity
-    o = ["s_waitcnt lgkmcnt(0)",
-         f"ds_read_b32 v{nl}, %[addr] offset:{off + 256}",   # next row's left
+    # LDS ops retire in order.  Outstanding here, oldest first: this row's two reads (issued one row ago), the
+    # previous row's write, and the two prefetches just issued -> lgkmcnt(3) waits for exactly the two reads
+    # this row needs and lets the write and the prefetches fly.  Every wave issues exactly one write per row
+    # (a wave without a right-hand neighbour writes into an unused ring) so that the count is static.
+    o = [f"ds_read_b32 v{nl}, %[addr] offset:{off + 256}",   # next row's left
          f"ds_read_b32 v{nd}, %[addr] offset:{off}",         # this row's left = next row's diag
+         "s_waitcnt lgkmcnt(3)",
          "s_bitcmp1_b32 %[qw], 1", f"s_cbranch_scc1 Lhi_{p}_%=",
          "s_bitcmp1_b32 %[qw], 0", f"s_cbranch_scc1 LC_{p}_%="]
     o += body(0, parity) + [f"s_branch Ljoin_{p}_%=", f"LC_{p}_%=:"]
@@ -90,8 +98,7 @@ def row(parity, wstride):
                             "s_bitcmp1_b32 %[qw], 0", f"s_cbranch_scc1 LT_{p}_%="]
     o += body(2, parity) + [f"s_branch Ljoin_{p}_%=", f"LT_{p}_%=:"]
     o += body(3, parity) + [f"Ljoin_{p}_%=:", "s_lshr_b32 %[qw], %[qw], 2",
-                            "s_bitcmp1_b32 %[n], 8", f"s_cbranch_scc0 Lnl_{p}_%=",
-                            f"ds_write_b32 %[addr], {h(15)} offset:{wstride + off}", f"Lnl_{p}_%=:",
+                            f"ds_write_b32 %[addr], {h(15)} offset:{wstride + off}",
                             "s_bitcmp1_b32 %[n], 9", f"s_cbranch_scc0 Lng_{p}_%=",
                             f"global_store_dword %[goff], {h(15)}, %[gb] sc1",
                             "v_add_u32_e32 %[goff], 0x100, %[goff]", f"Lng_{p}_%=:"]
@@ -102,6 +109,7 @@ def generate(wstride):
     o = [f"v_mov_b32_e32 v{D0}, %[diag]",
          f"ds_read_b32 v{L0}, %[addr]",
          "s_and_b32 %[i], %[n], 0xff",
+         "s_waitcnt lgkmcnt(0)",
          "Ltop_%=:"]
     o += row(0, wstride)
     o += ["s_sub_u32 %[i], %[i], 1", "s_cmp_eq_u32 %[i], 0", "s_cbranch_scc1 Lexit_%="]
@@ -119,7 +127,9 @@ def main():
     # ring geometry must match sw_score.hip: D slots x B rows x 256 bytes per wave
     Dslots, B = 2, 16
     lines = generate(Dslots * B * 256)
-    with open(os.path.join(here, "sw_score_asm.inc"), "w") as f:
+    if NO_NOPS:
+        lines = [ln for ln in lines if ln != "s_nop 0"]
+    with open(os.path.join(here, "sw_score_asm_nonops.inc" if NO_NOPS else "sw_score_asm.inc"), "w") as f:
         f.write("// GENERATED by gen_score_asm.py -- do not edit.  Row loop of sw_score_kernel (gfx950).\n")
         f.write(f"#define SW_SCORE_ASM_D {Dslots}\n#define SW_SCORE_ASM_B {B}\n")
         f.write("#define SW_SCORE_ROWS_ASM \\\n")

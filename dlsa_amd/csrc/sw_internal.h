@@ -90,5 +90,6 @@ struct ScoreParams {
 };
 hipError_t launch_score(const ScoreParams& p, int n_workgroups, hipStream_t stream);
 int score_waves_per_group();
+int score_workgroups_per_cu();
 
 }  // namespace swhip

@@ -707,7 +707,7 @@ int db_scores_locked(sw_db* db, const QueryPrep& qp, Scoring sc, std::vector<int
   } else {
     const uint32_t nblk = (Q + kScoreB - 1) / kScoreB;
     const size_t Qpad = (size_t)nblk * kScoreB;
-    const int nwg = (int)std::min<size_t>(db->n_units, (size_t)c.cus);
+    const int nwg = (int)std::min<size_t>(db->n_units, (size_t)c.cus * score_workgroups_per_cu());
     const uint32_t ring_slots = (uint32_t)std::max(2 * nwg, 2);
     const size_t gb_stride = Qpad * 64;
     int rc;
