@@ -28,7 +28,7 @@ struct ExactPair {
   uint32_t T0;        // last column computed for row x == 1
   uint32_t phaseQp;   // != 0: ring path with T < Qp, two-phase discovery order, value = Qp
   uint32_t straight;  // != 0: tie order of find_alignment_sequential_straight (smallest j, then x)
-  int32_t* bnd;       // scratch: 2 * bnd_pitch ints (H of the last row of the previous strip)
+  int32_t* bnd;       // scratch: nstrips rows of bnd_pitch ints (row s = bottom row of strip s)
   uint32_t bnd_pitch;
   uint32_t* dirs;     // nullptr: score + best cell only.  Else 2 bits per cell (layout in sw_exact.hip)
   uint32_t nkb;       // 16-step blocks per strip
@@ -50,7 +50,8 @@ inline size_t exact_dir_words(uint32_t Q, uint32_t maxcol) {
   return (size_t)exact_nstrips(Q) * (exact_nsteps(maxcol) / 16) * kExactRPL * 64;
 }
 
-hipError_t launch_exact(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, Scoring sc,
+// `waves`: wavefronts per pair (1..16); strips of a pair are spread over them
+hipError_t launch_exact(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, int waves, Scoring sc,
                         hipStream_t stream);
 hipError_t launch_walk(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, Scoring sc,
                        hipStream_t stream);

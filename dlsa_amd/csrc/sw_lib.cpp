@@ -201,6 +201,7 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
   std::vector<ExactPair> hp(n);
   std::vector<size_t> qoff(n), toff(n);
   size_t dir_words = 0, bnd_ints = 0, ops_bytes = 0;
+  uint32_t max_strips = 1;
   for (size_t i = 0; i < n; i++) {
     const PairSpec& s = specs[begin + i];
     qoff[i] = add_seq(s.q, s.Q);
@@ -218,7 +219,8 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
     e.nkb = exact_nsteps(maxcol) / 16;
     // temporarily store offsets in the pointer fields
     e.bnd = (int32_t*)(uintptr_t)bnd_ints;
-    bnd_ints += 2 * (size_t)e.bnd_pitch;
+    bnd_ints += (size_t)std::max<uint32_t>(exact_nstrips(s.Q), 1) * e.bnd_pitch;
+    max_strips = std::max(max_strips, exact_nstrips(s.Q));
     if (want_trace) {
       e.dirs = (uint32_t*)(uintptr_t)(dir_words + 1);  // +1 so that offset 0 is not nullptr
       dir_words += exact_dir_words(s.Q, maxcol);
@@ -251,12 +253,17 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
   if (!pool.empty()) HIPCK(hipMemcpyAsync(c.sym.p, pool.data(), pool.size() * 2, hipMemcpyHostToDevice, c.stream));
   HIPCK(hipMemcpyAsync(c.pairs.p, hp.data(), n * sizeof(ExactPair), hipMemcpyHostToDevice, c.stream));
   HIPCK(hipEventRecord(c.ev2, c.stream));
-  HIPCK(launch_exact((const ExactPair*)c.pairs.p, (ExactOut*)c.outs.p, (uint32_t)n, sc, c.stream));
+  // waves per pair: enough for the longest query of the chunk, fewer when many pairs fill the GPU anyway
+  int waves = (int)std::min<uint32_t>(max_strips, 16);
+  if (n >= (size_t)c.cus * 8) waves = std::min(waves, 4);
+  HIPCK(launch_exact((const ExactPair*)c.pairs.p, (ExactOut*)c.outs.p, (uint32_t)n, waves, sc, c.stream));
   if (want_trace) HIPCK(launch_walk((const ExactPair*)c.pairs.p, (ExactOut*)c.outs.p, (uint32_t)n, sc, c.stream));
   HIPCK(hipEventRecord(c.ev3, c.stream));
   std::vector<ExactOut> ho(n);
   HIPCK(hipMemcpyAsync(ho.data(), c.outs.p, n * sizeof(ExactOut), hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipStreamSynchronize(c.stream));
+  for (size_t i = 0; i < n; i++)
+    if (ho[i].nops == 0xffffffffu) return fail(SW_E_HIP, "exact kernel: strip pipeline wait timed out");
   float ms = 0;
   HIPCK(hipEventElapsedTime(&ms, c.ev2, c.ev3));
   c.stats.exact_kernel_ms += ms;
@@ -301,7 +308,8 @@ int run_exact(const PairSpec* specs, size_t n, Scoring sc, bool want_trace, Pair
     size_t end = begin, bytes = 0;
     while (end < n) {
       PathParams pp = resolve_path(specs[end].path, specs[end].Q, specs[end].T);
-      size_t b = (size_t)specs[end].Q * 2 + (size_t)specs[end].T * 10 + 256;
+      size_t b = (size_t)specs[end].Q * 2 + (size_t)specs[end].T * 2 +
+                 (size_t)std::max<uint32_t>(exact_nstrips(specs[end].Q), 1) * (specs[end].T + 2) * 4 + 256;
       if (want_trace) b += exact_dir_words(specs[end].Q, std::max(pp.Tlim, pp.T0)) * 4 + specs[end].Q + specs[end].T;
       if (end > begin && (bytes + b > c.scratch_budget || end - begin >= (1u << 20))) break;
       bytes += b;
