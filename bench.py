@@ -106,18 +106,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from dlsa_amd import shard
+    first_index = rank * n_targets  # weak scaling: every rank owns n_targets targets of the global database
+
     def step():
         hits = db.search_topk(query, score, TOP_K)
         st = bridge.last_stats()
-        if dist is not None:
-            rec = torch.tensor([[h["score"], rank * n_targets + h["target_index"], h["max_x"], h["max_y"]] for h in hits],
-                               dtype=torch.int64, device=dev)
-            allrec = [torch.empty_like(rec) for _ in range(world)]
-            dist.all_gather(allrec, rec)
-            merged = torch.cat(allrec).cpu().tolist()
-            merged.sort(key=lambda r: (-r[0], r[1]))
-            hits = merged[:TOP_K]
-        return hits, st
+        merged = shard.merge_topk(hits, TOP_K, first_index, dist, dev)
+        return merged, st
 
     for _ in range(args.warmup):
         step()
@@ -156,8 +152,7 @@ def main():
                          "kernel": "sw_score_kernel", "kernel_ms": k_ms,
                          "note": "6 algorithmic i16 ops/cell x Q*T cells per launch / HIP-event kernel time; "
                                  "the kernel executes 4.5 packed instructions per 2 cells"},
-            "top_hit": ({k: v for k, v in last[0].items() if not k.endswith("_aln")} if last and isinstance(last[0], dict)
-                        else (last[0] if last else None)),
+            "top_hit": (dict(zip(shard.RECORD_FIELDS, last[0])) if last else None),
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = max(1, min(16, (os.cpu_count() or 2)) - 1)

@@ -117,6 +117,8 @@ def lib():
     L.sw_hip_last_stats.argtypes = [C.POINTER(CStats)]
     L.sw_hip_last_stats.restype = C.c_int
     L.sw_hip_benchmark_cups.restype = C.c_float
+    L.sw_hip_path_params.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
+    L.sw_hip_path_params.restype = C.c_int
     _lib = L
     return L
 

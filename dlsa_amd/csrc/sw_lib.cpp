@@ -533,6 +533,16 @@ int sw_align_batch(const char* const* queries, const char* const* targets, size_
   return align_many(queries, targets, n_pairs, scores, path, out);
 }
 
+int sw_hip_path_params(int path, uint64_t q_len, uint64_t t_len, uint32_t out[4]) {
+  if (!out || path < 0 || path > 2 || q_len >= 0x7fffff00ull || t_len >= 0x7fffff00ull) return fail(SW_E_ARG, "bad argument");
+  const PathParams pp = resolve_path(path, (uint32_t)q_len, (uint32_t)t_len);
+  out[0] = pp.Tlim;
+  out[1] = pp.T0;
+  out[2] = pp.phaseQp;
+  out[3] = pp.straight;
+  return SW_OK;
+}
+
 int sw_hip_last_stats(sw_kernel_stats* out) {
   if (!out) return fail(SW_E_ARG, "null argument");
   std::lock_guard<std::mutex> lk(g_ctx.mu);

@@ -85,8 +85,6 @@ struct sw_hit {
  * the k best hits with full alignments.  *n_hits <= k.  Exact for every reported field. */
 int sw_db_search_topk(sw_db *db, const char *query, struct AlignmentScores scores, int k,
                       struct sw_hit *hits, int *n_hits);
-/* Same, additionally restricted to targets in [first, first+count) -- the shard a rank owns when the
- * database is split by target across GPUs. */
 /* All scores (int32, database order), for tests and for schedulers that want every pair. */
 int sw_db_scores(sw_db *db, const char *query, struct AlignmentScores scores, int32_t *scores_out);
 void sw_hits_free(struct sw_hit *hits, int n_hits);
@@ -107,6 +105,15 @@ int sw_hip_last_stats(struct sw_kernel_stats *out);
  * master/api_models/worker.py:7-16): cells per second of the batch path on synthetic DNA, as a
  * float32-representable INTEGER-valued number (the master's field is a pydantic int). */
 float sw_hip_benchmark_cups(void);
+
+/* ---- test hook (no GPU needed) ------------------------------------------------------------------------ */
+/* The four integers by which one plain Smith-Waterman reproduces a reference entry point for a pair of
+ * lengths (Q, T) (DESIGN.md "Effective semantics"): out[0] = last column computed for rows x >= 2,
+ * out[1] = last column computed for row x == 1, out[2] = Qp if the ring path's two-phase discovery order
+ * applies (else 0), out[3] = 1 for the straight entry's tie order.  Pure host arithmetic; lets the CPU test
+ * suite check the library's dispatch (rust/src/algorithm/mod.rs:213 and the padded-length quirks) against
+ * the oracle's clean model without a GPU. */
+int sw_hip_path_params(int path, uint64_t q_len, uint64_t t_len, uint32_t out[4]);
 
 #ifdef __cplusplus
 }

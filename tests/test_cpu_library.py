@@ -1,0 +1,110 @@
+"""CPU-side checks of the product library (no GPU, no compute calls): it builds for gfx950, loads, exports
+every symbol the headers declare, has the reference's struct layouts, refuses to compute without a GPU, and
+its path dispatch (host arithmetic) agrees with the oracle's clean model."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    from dlsa_amd import build, bridge
+    build.build()
+    return bridge.lib()
+
+
+def _declared_symbols():
+    names = set()
+    for h in ("sw.h", "sw_hip.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for m in re.finditer(r"\b([a-z_][a-z0-9_]*)\s*\(", src):
+            if m.group(1) not in ("defined", "sizeof"):
+                names.add(m.group(1))
+    return names
+
+
+def test_every_declared_symbol_is_exported(L):
+    names = _declared_symbols()
+    # the five symbols the Go worker binds (rust/src/bindings.rs:72,116,188,233,243) + the two stubs
+    for must in ("find_alignment_low_memory", "find_alignment_simd", "find_alignment_sequential_straight",
+                 "free_alignment_result", "free_c_string", "find_alignment_parallel", "find_alignment_sequential"):
+        assert must in names
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_struct_layouts_match_the_reference_header():
+    from dlsa_amd import bridge
+    # rust/header/sw.h:4-18 / rust/src/bindings.rs:9-16: Result is 40 bytes, AlignmentScores 6 bytes
+    assert C.sizeof(bridge.CResult) == 40
+    assert [getattr(bridge.CResult, f).offset for f in ("query_ptr", "target_ptr", "score", "max_x", "max_y")] == [0, 8, 16, 24, 32]
+    assert C.sizeof(bridge.CScores) == 6
+    assert [getattr(bridge.CScores, f).offset for f in ("gap", "match", "miss")] == [0, 2, 4]
+    s = bridge.AlignmentScore(2, -1, -1).c()   # the worker passes C.ushort(-penalty)
+    assert (s.gap, s.match, s.miss) == (0xFFFF, 2, 0xFFFF)
+
+
+def test_no_cpu_fallback(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from dlsa_amd import bridge
+    import dlsa_amd
+    res, err = dlsa_amd.find_alignment_with_fallback("ACGT", "ACGT", dlsa_amd.AlignmentScore(2, -1, -1))
+    assert res is None and err is not None
+    assert "no CPU fallback" in bridge.last_error() or "HIP" in bridge.last_error()
+    with pytest.raises(bridge.SwHipError):
+        bridge.Database(seqs=["ACGT"])
+    L.free_alignment_result(None)
+    L.free_c_string(None)
+
+
+def test_path_dispatch_matches_clean_model(L, oracle):
+    # The library's resolve_path (host arithmetic) vs the oracle's clean model on lengths around every
+    # boundary: T < 2Q dispatch, T % 64 == 0, Tp >= Qp, T < Qp.
+    out = (C.c_uint32 * 4)()
+
+    def params(path, Q, T):
+        assert L.sw_hip_path_params(path, Q, T, out) == 0
+        return tuple(out)
+
+    def expect(path, Q, T):
+        Qp, Tp = (Q + 63) // 64 * 64, (T + 63) // 64 * 64
+        if path == 2:
+            return (T, T, 0, 1)
+        full = path == 1 or T < 2 * Q
+        if full:
+            if T > 0 and T % 64 == 0:
+                return (T - 1, T if Tp >= Qp else T - 1, 0, 0)
+            return (T, T, 0, 0)
+        if T < Qp:
+            return (T, T - 1, Qp, 0)
+        return (T, T, 0, 0)
+
+    for Q in (0, 1, 2, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 1000):
+        for T in (0, 1, 2, 62, 63, 64, 65, 126, 127, 128, 129, 191, 192, 199, 200, 201, 256, 1999, 2000, 2001, 2048):
+            for path in (0, 1, 2):
+                assert params(path, Q, T) == expect(path, Q, T), (path, Q, T)
+    # ... and the clean model built on the same four integers equals the restatement (spot check here, the
+    # exhaustive comparison is tests/test_oracle_clean.py)
+    q, t = "A" + "G" * 20, "C" * 63 + "A"
+    a, c = oracle.align("simd", q, t, -1, 2, -1), oracle.clean_align(1, q, t, -1, 2, -1)
+    assert (a["q"], a["score"], a["max_x"], a["max_y"]) == (c["q"], c["score"], c["max_x"], c["max_y"]) == ("A", 2, 0, 63)
+    assert params(1, len(q), len(t)) == (63, 64, 0, 0)   # full path: column 64 only for row 1
+    assert params(0, len(q), len(t)) == (64, 64, 0, 0)   # T >= 2Q: ring path, no quirk
+
+
+def test_shard_ranges_cover_the_database():
+    from dlsa_amd import shard
+    for n in (0, 1, 7, 8, 100000, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
