@@ -38,6 +38,11 @@ MATCH, MISMATCH, GAP = 2, -1, -1           # as the worker passes them (worker_i
 OPS_PER_CELL = 6                            # algorithmic i16 ops per cell
 PEAK_TOPS = 78.6                            # 256 CU x 64 lanes/clk x 2 (packed) x 2.4 GHz, BASELINE.md 3
 SEED = 0xD15A
+# HBM-side bytes of one score-kernel launch on the default workload, from the PMC passes committed under
+# profiles/ (r01_pmc_summary.csv: WRITE_SIZE 5.87e6 KB + 2 x FETCH_SIZE 3.01e6 KB, the gfx950 half-count
+# corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes); counters cannot be read from inside
+# this process, so the figure is only attached when the shape is the profiled one.
+TRAFFIC_DEFAULT_BYTES = 5.8735e9 + 2 * 3.011e9
 
 
 def synth(rng, n, length):
@@ -148,7 +153,9 @@ def main():
                        "pairs_per_gpu": n_targets, "cells_per_gpu_per_step": cells_per_rank,
                        "parallelism": f"targets sharded over {world} GPU(s), top-k gather"},
             "roofline": {"bound": "valu-int16", "achieved": achieved, "peak": PEAK_TOPS, "unit": "T i16-op/s",
-                         "frac": achieved / PEAK_TOPS, "traffic": None,
+                         "frac": achieved / PEAK_TOPS,
+                         "traffic": (TRAFFIC_DEFAULT_BYTES if (Q_LEN, T_LEN, n_targets) == (10_000, 1_000, N_TARGETS)
+                                     else None),
                          "kernel": "sw_score_kernel", "kernel_ms": k_ms,
                          "note": "6 algorithmic i16 ops/cell x Q*T cells per launch / HIP-event kernel time; "
                                  "the kernel executes 4.5 packed instructions per 2 cells"},
@@ -156,7 +163,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = max(1, min(16, (os.cpu_count() or 2)) - 1)
-            out["cpu_baseline"] = cpu_baseline(query, flat, offsets, 6 * threads, threads)
+            out["cpu_baseline"] = cpu_baseline(query, flat, offsets, 72 * threads, threads)
         print(json.dumps(out))
     db.close()
     if dist is not None:
