@@ -47,7 +47,7 @@ def build(force=False, verbose=False):
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         subprocess.check_call(cmd)
         objs.append(obj)
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB] + objs)
     return LIB
 
 

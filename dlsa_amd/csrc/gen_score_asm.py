@@ -18,7 +18,8 @@ separated by an independent instruction or an s_nop.
 
 Row loop, unrolled by two so that the left/diag values alternate between (L0, D0) and (L1, D1) without moves:
 the left neighbour's column arrives through LDS at [addr + 256 * row]; the value a row needs as `left` is also
-the next row's `diag`, and is simply read twice.
+the next row's `diag`, and is simply read twice.  The wave's own last column leaves through [waddr + 256 * row]
+(the right neighbour's ring) and, when bit 9 of [n] is set, also through global memory.
 """
 import os
 import sys
@@ -80,7 +81,7 @@ def body(code, parity):
     return out
 
 
-def row(parity, wstride):
+def row(parity):
     p = "e" if parity == 0 else "o"
     nl, nd = (L1, D1) if parity == 0 else (L0, D0)
     off = 256 * parity
@@ -98,23 +99,24 @@ def row(parity, wstride):
                             "s_bitcmp1_b32 %[qw], 0", f"s_cbranch_scc1 LT_{p}_%="]
     o += body(2, parity) + [f"s_branch Ljoin_{p}_%=", f"LT_{p}_%=:"]
     o += body(3, parity) + [f"Ljoin_{p}_%=:", "s_lshr_b32 %[qw], %[qw], 2",
-                            f"ds_write_b32 %[addr], {h(15)} offset:{wstride + off}",
+                            f"ds_write_b32 %[waddr], {h(15)} offset:{off}",
                             "s_bitcmp1_b32 %[n], 9", f"s_cbranch_scc0 Lng_{p}_%=",
                             f"global_store_dword %[goff], {h(15)}, %[gb] sc1",
                             "v_add_u32_e32 %[goff], 0x100, %[goff]", f"Lng_{p}_%=:"]
     return o
 
 
-def generate(wstride):
+def generate():
     o = [f"v_mov_b32_e32 v{D0}, %[diag]",
          f"ds_read_b32 v{L0}, %[addr]",
          "s_and_b32 %[i], %[n], 0xff",
          "s_waitcnt lgkmcnt(0)",
          "Ltop_%=:"]
-    o += row(0, wstride)
+    o += row(0)
     o += ["s_sub_u32 %[i], %[i], 1", "s_cmp_eq_u32 %[i], 0", "s_cbranch_scc1 Lexit_%="]
-    o += row(1, wstride)
+    o += row(1)
     o += ["v_add_u32_e32 %[addr], 0x200, %[addr]",
+          "v_add_u32_e32 %[waddr], 0x200, %[waddr]",
           "s_sub_u32 %[i], %[i], 1", "s_cmp_lg_u32 %[i], 0", "s_cbranch_scc1 Ltop_%=",
           "Lexit_%=:",
           "s_waitcnt lgkmcnt(0)",   # the prefetches into L0/D0 have landed before the registers are released
@@ -126,7 +128,7 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     # ring geometry must match sw_score.hip: D slots x B rows x 256 bytes per wave
     Dslots, B = 2, 16
-    lines = generate(Dslots * B * 256)
+    lines = generate()
     if NO_NOPS:
         lines = [ln for ln in lines if ln != "s_nop 0"]
     with open(os.path.join(here, "sw_score_asm_nonops.inc" if NO_NOPS else "sw_score_asm.inc"), "w") as f:

@@ -61,36 +61,47 @@ constexpr int kScoreR = 16;       // target columns per wave (one 2-bit packed d
 constexpr int kScoreB = 16;       // query rows per hand-over block (one 2-bit packed dword of the query)
 constexpr int kGroupTargets = 128; // 64 lanes x 2 packed int16 halves
 
+// The packed database is one stream of STRIPS: all strips of group 0, then group 1, ...; strip e occupies
+// dwords [e*128, e*128+128) of `words` ([half][lane], 16 residues per dword).  A work unit is W consecutive
+// strips of that stream (W = waves per workgroup), whatever groups they belong to.  The stream is cut into
+// LANES (runs of whole groups that fill their last unit well); tickets visit S lanes round-robin, so the unit
+// that continues a group is handed out S tickets after the unit it depends on, when that one is well under
+// way -- its first wave does not sit waiting for the producer's last wave to get going.
 struct ScoreGroup {       // one group of up to 128 length-sorted targets
-  uint64_t word_off;      // offset (in dwords) of this group's packed residues: [strip][half][lane]
+  uint32_t strip_base;    // index of this group's first strip in the stream
   uint32_t nstrips;       // ceil(max length / 16)
-  uint32_t first_slot;    // index of lane 0 / half 0 in the per-slot arrays (lens, order); 128 slots
+  uint32_t first_slot;    // index of lane 0 / half 0 in the per-slot arrays (lens, scores); 128 slots
+  uint32_t pad_;
 };
 
-struct ScoreUnit {        // one work unit: W*16 target columns of one group against the whole query
-  uint32_t group;
-  uint32_t pass;
+struct ScoreUnit {        // ticket t -> what to do (built per search on the host, see build_units)
+  uint32_t first_elem;    // first strip of the stream
+  uint32_t count;         // strips (1..W); wave w takes strip first_elem + w
+  uint32_t dep;           // ticket of the unit that produces my wave 0's left column (~0u: none)
+  uint32_t reuse;         // ticket whose wave 0 must have released the boundary-ring slot I write (~0u: none)
 };
 
 struct ScoreParams {
-  const uint32_t* words;      // packed residues, 2 bits each, 16 per dword
+  const uint32_t* words;      // the strip stream
+  const ScoreUnit* units;     // n_units, in ticket order
+  const uint32_t* elem_group; // per strip of the stream: its group
   const ScoreGroup* groups;   // n_groups
   const uint32_t* lens;       // per slot: target length (0 for padding slots)
   const uint32_t* qwords;     // query, 2 bits per residue, 16 per dword (row-block aligned)
   uint32_t Q;
-  const ScoreUnit* units;     // n_units, ordered (group, pass)
   uint32_t n_units;
   int32_t* slot_scores;       // per slot: best H over the effective domain (32767 = saturated); zeroed
-  uint32_t* gbound;           // ring of inter-pass boundary columns: ring_slots * gbound_stride dwords
+  uint32_t* gbound;           // ring of inter-unit boundary columns: ring_slots * gbound_stride dwords
   uint64_t gbound_stride;     // dwords per ring slot (Q_pad * 64)
   uint32_t ring_slots;
-  uint32_t* prog;             // per unit: boundary blocks published / completion (zeroed before launch)
+  uint32_t* prog;             // 2 per unit: boundary blocks published / input slot released (zeroed)
   uint32_t* ticket;           // work counter (zeroed before launch)
-  uint32_t* err;              // set to 1 if a dependency wait timed out (zeroed before launch)
+  uint32_t* err;              // set != 0 if a dependency wait timed out (zeroed before launch)
   int match, miss, gap;
 };
 hipError_t launch_score(const ScoreParams& p, int n_workgroups, hipStream_t stream);
 int score_waves_per_group();
 int score_workgroups_per_cu();
+uint32_t score_queue_depth();  // units a workgroup may have in flight
 
 }  // namespace swhip

@@ -7,6 +7,8 @@
 // implementation of the alignment in this file: every cell is computed by a HIP kernel and a missing
 // GPU makes every entry point fail loudly (NULL / SW_E_NOGPU + sw_hip_last_error()).
 #include <algorithm>
+#include <array>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -15,6 +17,7 @@
 #include <mutex>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -566,8 +569,11 @@ struct sw_db {
   uint32_t* d_words = nullptr;
   uint32_t* d_lens = nullptr;
   ScoreGroup* d_groups = nullptr;
+  uint32_t* d_elem_group = nullptr;  // per strip of the stream: its group
+  uint32_t n_elems = 0;              // strips in the stream
+  // ticket-ordered unit table, rebuilt when the interleave / ring geometry of a search differs (build_units)
   ScoreUnit* d_units = nullptr;
-  uint32_t n_units = 0;
+  uint32_t n_units = 0, units_S = 0, units_R = 0;
   std::vector<uint32_t> generic;  // targets scored by the exact kernel only
   uint32_t max_len = 0;
 };
@@ -589,8 +595,23 @@ void db_release(sw_db* db) {
   if (db->d_words) (void)hipFree(db->d_words);
   if (db->d_lens) (void)hipFree(db->d_lens);
   if (db->d_groups) (void)hipFree(db->d_groups);
+  if (db->d_elem_group) (void)hipFree(db->d_elem_group);
   if (db->d_units) (void)hipFree(db->d_units);
   delete db;
+}
+
+// host threads for building a database (validation and 2-bit packing are byte loops over GBs)
+template <class F>
+void parallel_ranges(size_t n, F&& f) {
+  unsigned nt = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+  if (n < 4096) nt = 1;
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++) {
+    const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+    if (t + 1 == nt) f(lo, hi);
+    else th.emplace_back([=, &f] { f(lo, hi); });
+  }
+  for (auto& x : th) x.join();
 }
 
 sw_db* db_build(std::string&& flat, std::vector<uint64_t>&& off) {
@@ -600,30 +621,44 @@ sw_db* db_build(std::string&& flat, std::vector<uint64_t>&& off) {
   db->off = std::move(off);
   db->residues = db->off.back() - db->off.front();
   db->packed_ok.assign(db->n, 1);
-  std::vector<uint32_t> packable;
   for (uint64_t i = 0; i < db->n; i++) {
-    uint64_t len = db->off[i + 1] - db->off[i];
+    const uint64_t len = db->off[i + 1] - db->off[i];
     if (len >= 0x7fffff00ull) {
       db_release(db);
       fail(SW_E_ARG, "sequence too long");
       return nullptr;
     }
     db->max_len = std::max<uint32_t>(db->max_len, (uint32_t)len);
-    bool ok = true;
-    const unsigned char* s = (const unsigned char*)db->flat.data() + db->off[i];
-    for (uint64_t k = 0; k < len; k++) {
-      unsigned char ch = s[k];
-      if (ch >= 0x80 || ch == 0) {  // bytes are treated as one symbol each: ASCII only
-        if (ch == 0) {
-          db_release(db);
-          fail(SW_E_ARG, "NUL byte inside a sequence");
-          return nullptr;
-        }
+  }
+  // per target: 1 = only A/C/G/T (packable), 0 = something else (exact kernel), 2 = NUL inside
+  static const std::array<int8_t, 256> kCode = [] {
+    std::array<int8_t, 256> t;
+    t.fill(-1);
+    t['A'] = 0, t['C'] = 1, t['G'] = 2, t['T'] = 3;
+    return t;
+  }();
+  std::atomic<bool> has_nul{false};
+  parallel_ranges(db->n, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      const unsigned char* s = (const unsigned char*)db->flat.data() + db->off[i];
+      const uint64_t len = db->off[i + 1] - db->off[i];
+      int bad = 0, nul = 0;
+      for (uint64_t k = 0; k < len; k++) {
+        bad |= kCode[s[k]];  // any -1 sets the sign bit
+        nul |= (s[k] == 0);
       }
-      if (nt_code(ch) < 0) ok = false;
+      if (nul) has_nul = true;
+      db->packed_ok[i] = bad >= 0;
     }
-    db->packed_ok[i] = ok;
-    if (ok && len > 0) packable.push_back((uint32_t)i);
+  });
+  if (has_nul) {
+    db_release(db);
+    fail(SW_E_ARG, "NUL byte inside a sequence");
+    return nullptr;
+  }
+  std::vector<uint32_t> packable;
+  for (uint64_t i = 0; i < db->n; i++) {
+    if (db->packed_ok[i] && db->off[i + 1] > db->off[i]) packable.push_back((uint32_t)i);
     else db->generic.push_back((uint32_t)i);
   }
   // length-sorted (descending, stable on index) groups of 128
@@ -634,7 +669,7 @@ sw_db* db_build(std::string&& flat, std::vector<uint64_t>&& off) {
   db->groups.resize(ngroups);
   db->slot_target.assign(ngroups * kGroupTargets, UINT32_MAX);
   std::vector<uint32_t> lens(ngroups * kGroupTargets, 0);
-  size_t total_words = 0;
+  size_t total_strips = 0;
   for (size_t g = 0; g < ngroups; g++) {
     uint32_t maxlen = 0;
     for (int s = 0; s < kGroupTargets; s++) {
@@ -646,59 +681,119 @@ sw_db* db_build(std::string&& flat, std::vector<uint64_t>&& off) {
       lens[k] = len;
       maxlen = std::max(maxlen, len);
     }
-    db->groups[g].word_off = total_words;
-    db->groups[g].nstrips = (maxlen + kScoreR - 1) / kScoreR;
-    db->groups[g].first_slot = (uint32_t)(g * kGroupTargets);
-    total_words += (size_t)db->groups[g].nstrips * kGroupTargets;
-  }
-  std::vector<uint32_t> words(std::max<size_t>(total_words, 1), 0);
-  for (size_t g = 0; g < ngroups; g++) {
-    for (int s = 0; s < kGroupTargets; s++) {
-      size_t k = g * kGroupTargets + s;
-      uint32_t ti = db->slot_target[k];
-      if (ti == UINT32_MAX) continue;
-      const unsigned char* seq = (const unsigned char*)db->flat.data() + db->off[ti];
-      const uint32_t len = lens[k];
-      const int half = s / 64, lane = s % 64;
-      for (uint32_t strip = 0; strip * kScoreR < len; strip++) {
-        uint32_t w = 0;
-        for (int r = 0; r < kScoreR; r++) {
-          uint32_t col = strip * kScoreR + r;
-          if (col < len) w |= (uint32_t)nt_code(seq[col]) << (2 * r);
-        }
-        words[db->groups[g].word_off + ((size_t)strip * 2 + half) * 64 + lane] = w;
-      }
-    }
-  }
-  std::vector<ScoreUnit> units;
-  {
-    const uint32_t W = (uint32_t)score_waves_per_group();
-    for (size_t g = 0; g < ngroups; g++)
-      for (uint32_t pass = 0; pass * W < db->groups[g].nstrips; pass++) units.push_back(ScoreUnit{(uint32_t)g, pass});
-    db->n_units = (uint32_t)units.size();
-  }
-  if (ngroups) {
-    if (hipMalloc(&db->d_units, std::max<size_t>(units.size(), 1) * sizeof(ScoreUnit)) != hipSuccess ||
-        hipMemcpy(db->d_units, units.data(), units.size() * sizeof(ScoreUnit), hipMemcpyHostToDevice) != hipSuccess) {
+    if (total_strips > 0xfff00000ull) {
       db_release(db);
-      fail(SW_E_NOMEM, "hipMalloc failed for the database");
+      fail(SW_E_ARG, "database too large for one device (more than 2^32 strips)");
       return nullptr;
     }
+    db->groups[g].strip_base = (uint32_t)total_strips;
+    db->groups[g].nstrips = (maxlen + kScoreR - 1) / kScoreR;
+    db->groups[g].first_slot = (uint32_t)(g * kGroupTargets);
+    db->groups[g].pad_ = 0;
+    total_strips += db->groups[g].nstrips;
+  }
+  db->n_elems = (uint32_t)total_strips;
+  // the strip stream: strip e = dwords [e*128, e*128+128), [half][lane], 16 residues (2 bits each) per dword
+  std::vector<uint32_t> words(std::max<size_t>(total_strips * kGroupTargets, 1), 0);
+  std::vector<uint32_t> elem_group(std::max<size_t>(total_strips, 1), 0);
+  parallel_ranges(ngroups, [&](size_t glo, size_t ghi) {
+    for (size_t g = glo; g < ghi; g++) {
+      const ScoreGroup& G = db->groups[g];
+      for (uint32_t st = 0; st < G.nstrips; st++) elem_group[G.strip_base + st] = (uint32_t)g;
+      for (int s = 0; s < kGroupTargets; s++) {
+        size_t k = g * kGroupTargets + s;
+        uint32_t ti = db->slot_target[k];
+        if (ti == UINT32_MAX) continue;
+        const unsigned char* seq = (const unsigned char*)db->flat.data() + db->off[ti];
+        const uint32_t len = lens[k];
+        uint32_t* dst = words.data() + (size_t)G.strip_base * kGroupTargets + (size_t)(s / 64) * 64 + (s % 64);
+        uint32_t col = 0;
+        for (; col + kScoreR <= len; col += kScoreR, dst += kGroupTargets) {
+          uint32_t w = 0;
+          for (int r = 0; r < kScoreR; r++) w |= (uint32_t)kCode[seq[col + r]] << (2 * r);
+          *dst = w;
+        }
+        if (col < len) {
+          uint32_t w = 0;
+          for (int r = 0; col + r < len; r++) w |= (uint32_t)kCode[seq[col + r]] << (2 * r);
+          *dst = w;
+        }
+      }
+    }
+  });
+  if (ngroups) {
     if (hipMalloc(&db->d_words, words.size() * 4) != hipSuccess || hipMalloc(&db->d_lens, lens.size() * 4) != hipSuccess ||
-        hipMalloc(&db->d_groups, ngroups * sizeof(ScoreGroup)) != hipSuccess) {
+        hipMalloc(&db->d_groups, ngroups * sizeof(ScoreGroup)) != hipSuccess ||
+        hipMalloc(&db->d_elem_group, elem_group.size() * 4) != hipSuccess) {
       db_release(db);
       fail(SW_E_NOMEM, "hipMalloc failed for the database");
       return nullptr;
     }
     if (hipMemcpy(db->d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(db->d_lens, lens.data(), lens.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(db->d_groups, db->groups.data(), ngroups * sizeof(ScoreGroup), hipMemcpyHostToDevice) != hipSuccess) {
+        hipMemcpy(db->d_groups, db->groups.data(), ngroups * sizeof(ScoreGroup), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(db->d_elem_group, elem_group.data(), elem_group.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
       db_release(db);
       fail(SW_E_HIP, "hipMemcpy failed for the database");
       return nullptr;
     }
   }
   return db;
+}
+
+// Ticket order of the score kernel's work units.  The strip stream is cut into lanes (runs of whole groups,
+// cut where the last unit is nearly full); S lanes are active at a time and tickets visit them round-robin, so
+// consecutive units of one lane -- the only ones that depend on each other -- are S tickets apart.
+// R = slots of the boundary ring (slot of ticket t: t % R); `reuse` = the latest earlier reader of that slot.
+void build_units(const sw_db* db, uint32_t W, uint32_t S, uint32_t R, std::vector<ScoreUnit>& units) {
+  struct Lane { uint32_t pos, end, last_ticket; };
+  std::vector<Lane> lanes;
+  const size_t ng = db->groups.size();
+  const uint64_t approx_units = ((uint64_t)db->n_elems + W - 1) / W;
+  const uint64_t Lmin = std::min<uint64_t>(32, std::max<uint64_t>(2, approx_units / (4ull * S)));
+  const uint64_t Lmax = 4 * Lmin + 16;
+  for (size_t g = 0; g < ng;) {
+    uint64_t cum = 0;
+    size_t best = g;
+    double best_fill = -1;
+    for (size_t h = g; h < ng; h++) {
+      cum += db->groups[h].nstrips;
+      const uint64_t u = (cum + W - 1) / W;
+      if (u < Lmin && h + 1 < ng) continue;
+      const double fill = (double)cum / (double)(u * W);
+      if (fill > best_fill) best_fill = fill, best = h;
+      if (fill >= 0.995 || u >= Lmax) break;
+    }
+    lanes.push_back(Lane{db->groups[g].strip_base, db->groups[best].strip_base + db->groups[best].nstrips, UINT32_MAX});
+    g = best + 1;
+  }
+  units.clear();
+  units.reserve((size_t)approx_units + lanes.size());
+  std::vector<uint32_t> slot_reader(R, UINT32_MAX);
+  std::vector<size_t> active;
+  size_t next_lane = 0;
+  while (active.size() < S && next_lane < lanes.size()) active.push_back(next_lane++);
+  while (!active.empty()) {
+    for (size_t i = 0; i < active.size();) {
+      Lane& L = lanes[active[i]];
+      const uint32_t t = (uint32_t)units.size();
+      ScoreUnit u;
+      u.first_elem = L.pos;
+      u.count = std::min<uint32_t>(W, L.end - L.pos);
+      u.dep = L.last_ticket;
+      u.reuse = slot_reader[t % R];
+      if (u.dep != UINT32_MAX) slot_reader[u.dep % R] = t;
+      units.push_back(u);
+      L.pos += u.count;
+      L.last_ticket = t;
+      if (L.pos >= L.end) {
+        if (next_lane < lanes.size()) active[i++] = next_lane++;
+        else active.erase(active.begin() + (ptrdiff_t)i);
+      } else {
+        i++;
+      }
+    }
+  }
 }
 
 struct QueryPrep {
@@ -725,18 +820,37 @@ int db_scores_locked(sw_db* db, const QueryPrep& qp, Scoring sc, std::vector<int
   } else {
     const uint32_t nblk = (Q + kScoreB - 1) / kScoreB;
     const size_t Qpad = (size_t)nblk * kScoreB;
-    const int nwg = (int)std::min<size_t>(db->n_units, (size_t)c.cus * score_workgroups_per_cu());
-    const uint32_t ring_slots = (uint32_t)std::max(2 * nwg, 2);
+    const uint32_t W = (uint32_t)score_waves_per_group();
+    const uint32_t max_wg = (uint32_t)c.cus * (uint32_t)score_workgroups_per_cu();
+    // interleave: a unit should be handed out about 40 blocks after the unit it continues, i.e. when that
+    // one's last wave is publishing; max_wg workgroups draw max_wg tickets per (nblk + drain) blocks
+    const uint32_t S = std::min<uint32_t>(1024, std::max<uint32_t>(8, max_wg * 40 / (nblk + 16)));
+    // boundary ring: a workgroup has at most 1 + queue depth units in flight, fewer when a unit is long
+    const uint32_t ahead = std::min<uint32_t>(score_queue_depth(), 48 / nblk + 1);
+    const uint32_t ring_slots = S + max_wg * (1 + ahead) + 8;
+    if (db->units_S != S || db->units_R != ring_slots || !db->d_units) {
+      std::vector<ScoreUnit> units;
+      build_units(db, W, S, ring_slots, units);
+      if (db->d_units) (void)hipFree(db->d_units);
+      db->d_units = nullptr;
+      if (hipMalloc(&db->d_units, std::max<size_t>(units.size(), 1) * sizeof(ScoreUnit)) != hipSuccess)
+        return fail(SW_E_NOMEM, "hipMalloc failed for the unit table");
+      HIPCK(hipMemcpy(db->d_units, units.data(), units.size() * sizeof(ScoreUnit), hipMemcpyHostToDevice));
+      db->n_units = (uint32_t)units.size();
+      db->units_S = S;
+      db->units_R = ring_slots;
+    }
+    const int nwg = (int)std::min<uint32_t>(db->n_units, max_wg);
     const size_t gb_stride = Qpad * 64;
     int rc;
     if ((rc = c.qwords.ensure(qp.qwords.size() * 4))) return rc;
     if ((rc = c.slot_scores.ensure(db->slot_target.size() * 4))) return rc;
     if ((rc = c.gbound.ensure((size_t)ring_slots * gb_stride * 4))) return rc;
     if ((rc = c.ticket.ensure(256))) return rc;
-    if ((rc = c.prog.ensure(std::max<size_t>(db->n_units * 4, 16)))) return rc;
+    if ((rc = c.prog.ensure(std::max<size_t>((size_t)db->n_units * 8, 16)))) return rc;
     HIPCK(hipMemcpyAsync(c.qwords.p, qp.qwords.data(), qp.qwords.size() * 4, hipMemcpyHostToDevice, c.stream));
     HIPCK(hipMemsetAsync(c.ticket.p, 0, 256, c.stream));
-    HIPCK(hipMemsetAsync(c.prog.p, 0, std::max<size_t>(db->n_units * 4, 16), c.stream));
+    HIPCK(hipMemsetAsync(c.prog.p, 0, std::max<size_t>((size_t)db->n_units * 8, 16), c.stream));
     HIPCK(hipMemsetAsync(c.slot_scores.p, 0, db->slot_target.size() * 4, c.stream));
     ScoreParams p{};
     p.words = db->d_words;
@@ -744,6 +858,7 @@ int db_scores_locked(sw_db* db, const QueryPrep& qp, Scoring sc, std::vector<int
     p.lens = db->d_lens;
     p.qwords = (const uint32_t*)c.qwords.p;
     p.Q = Q;
+    p.elem_group = db->d_elem_group;
     p.units = db->d_units;
     p.n_units = db->n_units;
     p.slot_scores = (int32_t*)c.slot_scores.p;
@@ -764,7 +879,7 @@ int db_scores_locked(sw_db* db, const QueryPrep& qp, Scoring sc, std::vector<int
     uint32_t kerr = 0;
     HIPCK(hipMemcpyAsync(&kerr, (uint32_t*)c.ticket.p + 32, 4, hipMemcpyDeviceToHost, c.stream));
     HIPCK(hipStreamSynchronize(c.stream));
-    if (kerr) return fail(SW_E_HIP, "score kernel: a pass-chain dependency wait timed out");
+    if (kerr) return fail(SW_E_HIP, "score kernel: a dependency wait timed out");
     float ms = 0;
     HIPCK(hipEventElapsedTime(&ms, c.ev0, c.ev1));
     c.stats.score_kernel_ms += ms;

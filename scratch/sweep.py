@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Shape sweep on the GPU box: the other BASELINE.json configurations through the same C ABI."""
+import sys, os, time, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import dlsa_amd
+from dlsa_amd import bridge
+
+def synth(rng, lens):
+    lut = np.frombuffer(b"ATCG", dtype=np.uint8)
+    offs = np.zeros(len(lens) + 1, dtype=np.uint64); offs[1:] = np.cumsum(lens)
+    flat = lut[rng.integers(0, 4, size=int(offs[-1]), dtype=np.uint8)]
+    return flat, offs
+
+def db_case(name, qlen, lens, reps=2):
+    rng = np.random.default_rng(7)
+    q = synth(rng, np.array([qlen]))[0].tobytes()
+    flat, offs = synth(rng, lens)
+    t0 = time.perf_counter(); db = bridge.Database(flat=flat, offsets=offs); tb = time.perf_counter() - t0
+    sc = dlsa_amd.AlignmentScore(2, -1, -1)
+    best = 1e9
+    for _ in range(reps + 1):
+        t0 = time.perf_counter(); hits = db.search_topk(q, sc, 5); dt = time.perf_counter() - t0
+        best = min(best, dt)
+    st = bridge.last_stats()
+    cells = float(qlen) * float(lens.sum())
+    print(json.dumps({"case": name, "pairs": len(lens), "cells": cells, "db_build_s": round(tb, 3), "search_ms": round(best * 1e3, 3),
+                      "gcups": round(cells / best / 1e9, 1), "stats": st, "top": hits[0]["score"] if hits else None}), flush=True)
+    db.close()
+
+def pair_case(name, Q, T, mutate=None):
+    rng = np.random.default_rng(11)
+    q = synth(rng, np.array([Q]))[0]
+    if mutate is None:
+        t = synth(rng, np.array([T]))[0]
+    else:
+        t = q.copy()[:T]; idx = rng.random(T) < mutate; t[idx] = np.frombuffer(b"ATCG", dtype=np.uint8)[rng.integers(0, 4, size=int(idx.sum()))]
+    sc = dlsa_amd.AlignmentScore(2, -1, -1)
+    t0 = time.perf_counter(); r = bridge.align_batch([q.tobytes()], [t.tobytes()], sc, 0); dt = time.perf_counter() - t0
+    r0 = r[0]
+    print(json.dumps({"case": name, "Q": Q, "T": T, "s": round(dt, 3), "gcups": round(Q * T / dt / 1e9, 2),
+                      "score": None if r0 is None else r0.score, "alen": None if r0 is None else len(r0.query)}), flush=True)
+
+which = sys.argv[1:]
+rng = np.random.default_rng(3)
+if "c1" in which: db_case("C1 1kb x 1000x[900,1100]", 1000, rng.integers(900, 1101, size=1000))
+if "c1big" in which: db_case("1kb x 100000x[900,1100]", 1000, rng.integers(900, 1101, size=100000))
+if "c3" in which: db_case("C3 (1 of 32 queries) 1kb x 1e6xU[200,5000]", 1000, rng.integers(200, 5001, size=1000000))
+if "c5" in which: db_case("C5 (1 of 1000 queries) 150 x 1e7x150", 150, np.full(10000000, 150))
+if "c5s" in which: db_case("C5 scaled 150 x 1e6x150", 150, np.full(1000000, 150))
+if "p20k" in which: pair_case("pair 20k", 20000, 20000)
+if "p50k" in which: pair_case("pair 50k", 50000, 50000)
+if "c4" in which: pair_case("C4 100k", 100000, 100000)
+if "c4m" in which: pair_case("C4 100k 5% mutated", 100000, 100000, 0.05)
