@@ -5,9 +5,10 @@
 // (ring path) and algorithm/mod.rs:518-549 + lib.rs:55-70 (straight), with the traceback priority of
 // algorithm/mod.rs:665-706.  It is not a translation: the reference fills a skewed i16 matrix row by
 // row; here a 64-lane wavefront sweeps a strip of 256 query rows (4 per lane) along the target as an
-// anti-diagonal wavefront and passes H across lanes with a DPP wave shift; the up-to-16 waves of a
-// workgroup take consecutive strips of one pair and pipeline along the target (strip boundary rows in HBM,
-// progress counters in LDS); only 2 direction bits per cell are kept for the traceback walker.
+// anti-diagonal wavefront and passes H across lanes with a DPP wave shift; every strip of a pair has its own
+// wave and the strips pipeline along the target across the whole GPU (strip boundary rows and progress words
+// in HBM at device scope, tickets in (pair, strip) order); only 2 direction bits per cell are kept for the
+// traceback walker.
 //
 // Arithmetic: int32 (the "int32 re-run" of the north star; equal to the reference's wrapping i16 on its
 // safe domain max H <= 32767).
@@ -43,138 +44,192 @@ __device__ __forceinline__ uint64_t order_key(uint32_t x, uint32_t j, uint32_t T
   return (p << 63) | ((uint64_t)(x + j) << 31) | x;
 }
 
-// bounded spin on an LDS progress word of the wave that owns the strip above mine
-__device__ __forceinline__ void wait_strip(const uint32_t* f, uint32_t need, uint32_t* err) {
-  for (uint32_t spin = 0; spin < (1u << 26); spin++) {
-    if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) {
-      asm volatile("" ::: "memory");
-      return;
-    }
-    __builtin_amdgcn_s_sleep(2);
-  }
-  *err = 1;
+// ---- strip-to-strip hand-over ---------------------------------------------------------------------------
+// The bottom row of strip s is the top boundary of strip s+1.  It travels through one HBM row per strip; the
+// waves may sit on different CUs and XCDs, so stores and loads are device-scope.  There are no flags: every
+// boundary word carries its own "published" tag in bit 31 (H is a non-negative int32, so the bit is free; the
+// rows are zeroed before the launch).  The producer stores 16 tagged values every 16 steps and never waits for
+// them; the consumer fetches the 16 values of its NEXT 16-step block while it computes the current one and
+// re-polls only if a tag is still missing.  A dword store is atomic, so a tagged word is a complete value.
+constexpr uint32_t kTag = 0x80000000u;
+
+// Two direction bits of one cell appended to the lane's accumulator: acc = acc * 4 + 2 * (a1 >= b1) + (a0 == b0).
+// v_cmp into an SGPR pair + v_addc (acc + acc + carry) is one instruction per bit instead of cndmask + shift + or.
+// The compiler cannot see inside the statement, so the two wait states gfx950 needs between a VALU write of an
+// SGPR and a VALU read of it are provided here: each v_addc is two issue slots behind its v_cmp.
+__device__ __forceinline__ uint32_t push_dir_bits(uint32_t acc, int a1, int b1, int a0, int b0) {
+  uint64_t m1, m0;
+  asm("v_cmp_ge_i32 %1, %3, %4\n\t"
+      "v_cmp_eq_u32 %2, %5, %6\n\t"
+      "s_nop 0\n\t"
+      "v_addc_co_u32 %0, vcc, %0, %0, %1\n\t"
+      "v_addc_co_u32 %0, vcc, %0, %0, %2"
+      : "+v"(acc), "=&s"(m1), "=&s"(m0)
+      : "v"(a1), "v"(b1), "v"(a0), "v"(b0)
+      : "vcc");
+  return acc;
 }
 
-// One pair per workgroup.  The NW waves of the workgroup own consecutive 256-row strips (wave w: strips w,
-// w + NW, ...) and run as a pipeline along the target: a strip may enter column block c once the strip above
-// it has left it, i.e. 128 steps later (64 lanes of skew + 64-column hand-over blocks).  The bottom row of
-// every strip goes through one HBM row per strip (same CU, same L2: plain stores, L1-bypassing loads);
-// progress counters live in LDS.
+// One 256-row strip of one pair per WAVE.  Tickets are drawn in (pair, strip) order, so the strip above mine
+// always belongs to an earlier ticket: its wave is resident or has finished, whatever the dispatch order, and
+// the chain of strips cannot deadlock.  All strips of a pair run concurrently as a pipeline along the target,
+// spread over the whole GPU; strip s trails strip s-1 by about 100 steps (64 lanes of skew + one 16-column
+// hand-over block + the prefetch distance).
+//
+// 16 steps of the wavefront.  MASK = false is the interior of the matrix (every column any lane touches is
+// <= min(Tlim, T0), miss < 0 and gap < 0): cells outside the matrix (columns < 1 of lanes that have not
+// started, rows >= Q of the last strip) need no masking there, because with sentinel symbols that never match
+// they evaluate to 0 from zero inputs, and phantom rows below the matrix only see values strictly smaller than
+// a real cell's, so they never win the maximum.  MASK = true handles the right edge and odd scorings.
+template <bool DIRS, bool MASK>
+__device__ __forceinline__ void exact_steps16(const uint32_t (&qs)[RPL], const bool (&valid)[RPL], int (&h)[RPL],
+                                              int (&bestv)[RPL], uint32_t (&bestj)[RPL], uint32_t (&acc)[RPL],
+                                              int& top_prev, int& last_out, int& tcur, int (&hist)[16], int& jv,
+                                              int bcur, int tblk, int match, int miss, int gap, uint32_t lim0,
+                                              uint32_t Tlim) {
+#pragma unroll
+  for (int k4 = 0; k4 < 16; k4++) {
+    const int s_b = __builtin_amdgcn_readlane(bcur, k4);
+    const int s_t = __builtin_amdgcn_readlane(tblk, k4);
+    const int top = dpp_wave_shr1(s_b, last_out);  // H(row above this lane, column j)
+    tcur = dpp_wave_shr1(s_t, tcur);               // target symbol of column j
+    // everything that does not depend on this step's cell above: diag + s, left + gap, their max with 0
+    int d[RPL], lfg[RPL], m[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; r++) {
+      const int sc = ((int)qs[r] == tcur) ? match : miss;
+      d[r] = (r == 0 ? top_prev : h[r - 1]) + sc;
+      lfg[r] = h[r] + gap;
+      m[r] = max(max(d[r], lfg[r]), 0);
+    }
+    // the dependent chain down the lane's rows: two operations per cell
+    int upg = top + gap;
+#pragma unroll
+    for (int r = 0; r < RPL; r++) {
+      int hn = max(m[r], upg);
+      if (MASK) {
+        const uint32_t lim = (r == 0) ? lim0 : Tlim;
+        const bool act = valid[r] && jv >= 1 && (uint32_t)jv <= lim;
+        hn = act ? hn : 0;
+      }
+      if (DIRS) {
+        // bit 1: up >= left; bit 0: the diagonal wins (for H > 0: H == diag + s  <=>  diag + s >= max(up, left) + gap)
+        acc[r] = push_dir_bits(acc[r], upg, lfg[r], hn, d[r]);
+      }
+      if (hn > bestv[r]) bestj[r] = (uint32_t)jv;  // strict: the first (smallest j) maximal cell of the row
+      bestv[r] = max(bestv[r], hn);
+      h[r] = hn;
+      upg = hn + gap;
+    }
+    top_prev = top;
+    last_out = h[RPL - 1];
+    // bottom row of the strip leaves through lane 63: column k - 62 at step k; already tagged for the hand-over
+    hist[k4] = (int)((uint32_t)last_out | kTag);
+    jv++;
+  }
+}
+
 template <bool DIRS>
-__device__ __forceinline__ void exact_pair(const ExactPair& P, ExactOut* out, int match, int miss, int gap,
-                                           uint32_t* prog, uint32_t* red, uint32_t* err) {
+__device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork& W, uint32_t strip, int match,
+                                            int miss, int gap, int& gbv, uint64_t& gkey) {
   const int lane = threadIdx.x & 63;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint32_t NW = blockDim.x >> 6;
   const uint32_t Q = P.Q, T = P.T;
   const uint32_t maxcol = P.Tlim > P.T0 ? P.Tlim : P.T0;
-  const uint32_t nsteps = maxcol == 0 ? 0 : ((maxcol + 63 + 63) / 64) * 64;
-  const uint32_t NC = nsteps / 64;  // hand-over events per strip
-  const uint32_t nstrips = (Q + SH - 1) / SH;
+  const uint32_t mincol = P.Tlim < P.T0 ? P.Tlim : P.T0;
+  const uint32_t NG = exact_nsteps(maxcol) / 16;  // 16-step blocks
+  const uint32_t nstrips = exact_nstrips(Q);
 
-  int gbv = 0;
-  uint64_t gkey = ~0ull;
-
-  if (threadIdx.x < 16) prog[threadIdx.x] = 0;
-  __syncthreads();
-
-  for (uint32_t pass = 0, strip = wave; strip < nstrips && nsteps; pass++, strip += NW) {
-    const int32_t* bin = P.bnd + (size_t)(strip > 0 ? strip - 1 : 0) * P.bnd_pitch;  // bottom row of strip-1
-    int32_t* bout = P.bnd + (size_t)strip * P.bnd_pitch;
-    // the strip above me belongs to wave-1 in this pass, or to the last wave in the previous pass
-    const uint32_t* pflag = prog + (wave > 0 ? wave - 1 : NW - 1);
-    const uint32_t pbase = (wave > 0 ? pass : pass - 1) * NC;
-    const uint32_t ibase = strip * SH + lane * RPL;  // 0-based first row of this lane
-    uint32_t qs[RPL];
-    bool valid[RPL];
-    int h[RPL], bestv[RPL];
-    uint32_t bestj[RPL], acc[RPL];
+  const int32_t* bin = P.bnd + (size_t)(strip > 0 ? strip - 1 : 0) * P.bnd_pitch;  // bottom row of strip-1
+  int32_t* bout = P.bnd + (size_t)strip * P.bnd_pitch;
+  const bool chained = strip > 0;
+  const bool feeds = strip + 1 < nstrips;
+  const bool plain = miss < 0 && gap < 0;          // MASK = false is legal in the interior
+  const uint32_t ibase = strip * SH + lane * RPL;  // 0-based first row of this lane
+  uint32_t qs[RPL];
+  bool valid[RPL];
+  int h[RPL], bestv[RPL];
+  uint32_t bestj[RPL], acc[RPL];
 #pragma unroll
-    for (int r = 0; r < RPL; r++) {
-      uint32_t i = ibase + r;
-      valid[r] = i < Q;
-      qs[r] = valid[r] ? P.q[i] : 0x10000u;  // never equals a u16 symbol
-      h[r] = 0;
-      bestv[r] = 0;
-      bestj[r] = 0;
-      acc[r] = 0;
+  for (int r = 0; r < RPL; r++) {
+    uint32_t i = ibase + r;
+    valid[r] = i < Q;
+    qs[r] = valid[r] ? P.q[i] : 0x10000u;  // never equals a u16 symbol
+    h[r] = 0;
+    bestv[r] = 0;
+    bestj[r] = 0;
+    acc[r] = 0;
+  }
+  const bool row1_lane = (strip == 0) && (lane == 0);
+  const uint32_t lim0 = row1_lane ? P.T0 : P.Tlim;  // column limit of this lane's row r == 0
+  int top_prev = 0, last_out = 0;
+  int hist[16];
+  int tcur = 0x20000;
+  int jv = 1 - lane;  // the column this lane works on
+
+  // lane l (mod 16) fetches what lane 0 needs at step 16 g + l: the boundary and the symbol of column 16 g + l + 1
+  auto fetch_bnd = [&](uint32_t g) -> int {
+    const uint32_t col = g * 16 + (lane & 15) + 1;
+    if (!chained || col > maxcol) return (int)kTag;
+    return __hip_atomic_load(bin + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto fetch_t = [&](uint32_t g) -> int {
+    const uint32_t col = g * 16 + (lane & 15) + 1;
+    return (col <= T) ? (int)P.t[col - 1] : 0x20000;
+  };
+  int bnext = fetch_bnd(0), tnext = fetch_t(0);
+  for (uint32_t g = 0; g < NG; g++) {
+    // the boundary of this block must be complete; normally it is (fetched 16 steps ago)
+    for (uint32_t spin = 0; __builtin_amdgcn_ballot_w64(((uint32_t)bnext & kTag) == 0) != 0; spin++) {
+      if (spin >= (1u << 22)) {  // a bug, not a legal state: let the grid drain and report
+        __hip_atomic_store(W.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+      bnext = fetch_bnd(g);
     }
-    const bool row1_lane = (strip == 0) && (lane == 0);
-    const uint32_t lim0 = row1_lane ? P.T0 : P.Tlim;  // column limit of this lane's row r == 0
-    int top_prev = 0, last_out = 0, bndreg = 0, outacc = 0;
-    int tcur = 0x20000, tblock = 0;
-
-    for (uint32_t k = 0; k < nsteps; k++) {
-      if ((k & 63) == 0) {
-        uint32_t jj = k + lane + 1;  // the column lane 0 reaches at step k + lane
-        if (strip > 0) {
-          // columns k+1 .. k+64 of the row above left its wave at step k + 127: event (k / 64) + 2
-          const uint32_t ev = (k >> 6) + 2;
-          wait_strip(pflag, pbase + (ev < NC ? ev : NC), err);
-          bndreg = (jj <= maxcol) ? __hip_atomic_load(bin + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-        } else {
-          bndreg = 0;
-        }
-        tblock = (jj <= T) ? (int)P.t[jj - 1] : 0x20000;
-      }
-      const int s_b = __builtin_amdgcn_readlane(bndreg, k & 63);
-      const int s_t = __builtin_amdgcn_readlane(tblock, k & 63);
-      const int top = dpp_wave_shr1(s_b, last_out);  // H(row above this lane, column j)
-      tcur = dpp_wave_shr1(s_t, tcur);               // target symbol of column j
-      const int j = (int)k - lane + 1;
-      int up = top, dg = top_prev;
-#pragma unroll
-      for (int r = 0; r < RPL; r++) {
-        const int lf = h[r];
-        const int sc = ((int)qs[r] == tcur) ? match : miss;
-        const int d = dg + sc;
-        const int t2 = max(up, lf) + gap;
-        int hn = max(max(d, t2), 0);
-        const uint32_t lim = (r == 0) ? lim0 : P.Tlim;
-        const bool act = valid[r] && j >= 1 && (uint32_t)j <= lim;
-        hn = act ? hn : 0;
-        if (DIRS) {
-          const uint32_t code = (d >= t2 ? 1u : 0u) | (up >= lf ? 2u : 0u);
-          acc[r] = (acc[r] << 2) | code;
-        }
-        if (hn > bestv[r]) {  // strict: keeps the first (smallest j) maximal cell of the row
-          bestv[r] = hn;
-          bestj[r] = (uint32_t)j;
-        }
-        dg = lf;
-        up = hn;
-        h[r] = hn;
-      }
-      top_prev = top;
-      last_out = h[RPL - 1];
-      // bottom row of the strip leaves through lane 63: column k - 62 at step k
-      const int s_o = __builtin_amdgcn_readlane(last_out, 63);
-      outacc = (lane == (int)(k & 63)) ? s_o : outacc;
-      if ((k & 63) == 63) {
-        if (strip + 1 < nstrips) {
-          const int col = (int)k - 125 + lane;
-          if (col >= 1 && (uint32_t)col <= maxcol) bout[col] = outacc;
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row segment is in L2 before the counter moves
-        }
-        if (lane == 0)
-          __hip_atomic_store(prog + wave, pass * NC + (k >> 6) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      if (DIRS && (k & 15) == 15) {
-        uint32_t* w = P.dirs + ((size_t)(strip * P.nkb + (k >> 4)) * RPL) * 64 + lane;
-#pragma unroll
-        for (int r = 0; r < RPL; r++) w[r * 64] = acc[r];
-      }
+    const int bcur = (int)((uint32_t)bnext & ~kTag), tblk = tnext;
+    if (g + 1 < NG) {
+      bnext = fetch_bnd(g + 1);
+      tnext = fetch_t(g + 1);
     }
+    if (plain && g * 16 + 16 <= mincol)
+      exact_steps16<DIRS, false>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
+                                 match, miss, gap, lim0, P.Tlim);
+    else
+      exact_steps16<DIRS, true>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
+                                match, miss, gap, lim0, P.Tlim);
+    if (DIRS) {
+      uint32_t* w = P.dirs + ((size_t)(strip * P.nkb + g) * RPL) * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < RPL; r++) {
-      const uint64_t key = order_key(ibase + r + 1, bestj[r], T, P.phaseQp, P.straight);
-      if (bestv[r] > gbv || (bestv[r] == gbv && bestv[r] > 0 && key < gkey)) {
-        gbv = bestv[r];
-        gkey = key;
+      for (int r = 0; r < RPL; r++) w[r * 64] = acc[r];
+    }
+    if (feeds && lane == 63) {
+      // lane 63 finished columns 16 g - 62 .. 16 g - 47 of the strip's bottom row during this block
+      const int col0 = (int)(g * 16) - 62;
+      if (col0 >= 1 && (uint32_t)(col0 + 15) <= maxcol) {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          __hip_atomic_store(bout + col0 + i, hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+          if (col0 + i >= 1 && (uint32_t)(col0 + i) <= maxcol)
+            __hip_atomic_store(bout + col0 + i, hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
-  // wave reduction with the reference's tie order
+#pragma unroll
+  for (int r = 0; r < RPL; r++) {
+    const uint64_t key = order_key(ibase + r + 1, bestj[r], T, P.phaseQp, P.straight);
+    if (bestv[r] > gbv || (bestv[r] == gbv && bestv[r] > 0 && key < gkey)) {
+      gbv = bestv[r];
+      gkey = key;
+    }
+  }
+}
+
+// (score, key) with the reference's tie order: larger score, then smaller key
+__device__ __forceinline__ void wave_best(int& gbv, uint64_t& gkey) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     const int ov = __shfl_xor(gbv, off);
@@ -185,106 +240,184 @@ __device__ __forceinline__ void exact_pair(const ExactPair& P, ExactOut* out, in
       gkey = okey;
     }
   }
-  // ... then across the workgroup's waves
-  if (lane == 0) {
-    red[wave * 3 + 0] = (uint32_t)gbv;
-    red[wave * 3 + 1] = (uint32_t)gkey;
-    red[wave * 3 + 2] = (uint32_t)(gkey >> 32);
+}
+
+__global__ void __launch_bounds__(64) sw_exact_kernel(ExactWork W, int match, int miss, int gap) {
+  const int lane = threadIdx.x;
+  uint32_t t = 0;
+  if (lane == 0) t = atomicAdd(W.ticket, 1u);
+  const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+  if (ticket >= W.n_units) return;
+  const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.unit_pair[ticket]);
+  const ExactPair P = W.pairs[p];
+  const uint32_t strip = ticket - P.first_unit;
+  const uint32_t maxcol = P.Tlim > P.T0 ? P.Tlim : P.T0;
+  int gbv = 0;
+  uint64_t gkey = ~0ull;
+  if (strip < exact_nstrips(P.Q) && maxcol > 0) {
+    if (P.dirs)
+      exact_strip<true>(P, W, strip, match, miss, gap, gbv, gkey);
+    else
+      exact_strip<false>(P, W, strip, match, miss, gap, gbv, gkey);
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (uint32_t w = 1; w < NW; w++) {
-      const int ov = (int)red[w * 3];
-      const uint64_t okey = ((uint64_t)red[w * 3 + 2] << 32) | red[w * 3 + 1];
-      if (ov > gbv || (ov == gbv && okey < gkey)) {
-        gbv = ov;
-        gkey = okey;
-      }
+  wave_best(gbv, gkey);
+  // The last strip of a pair to finish combines the per-strip records (threadfence reduction).
+  if (lane == 0) {
+    __hip_atomic_store(&W.recs[ticket].score, gbv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&W.recs[ticket].key_lo, (uint32_t)gkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&W.recs[ticket].key_hi, (uint32_t)(gkey >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  uint32_t prev = 0;
+  if (lane == 0) prev = __hip_atomic_fetch_add(W.pair_done + p, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  prev = (uint32_t)__builtin_amdgcn_readfirstlane((int)prev);
+  if (prev + 1 != P.n_units) return;
+  gbv = 0;
+  gkey = ~0ull;
+  for (uint32_t u = lane; u < P.n_units; u += 64) {
+    const ExactRec* r = W.recs + P.first_unit + u;
+    const int ov = __hip_atomic_load(&r->score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t okey = ((uint64_t)__hip_atomic_load(&r->key_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 32) |
+                          __hip_atomic_load(&r->key_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ov > gbv || (ov == gbv && okey < gkey)) {
+      gbv = ov;
+      gkey = okey;
     }
+  }
+  wave_best(gbv, gkey);
+  if (lane == 0) {
     uint32_t bx = 0, bj = 0;
     if (gbv > 0) {
       bx = (uint32_t)(gkey & 0x7fffffffu);
       const uint32_t hi = (uint32_t)((gkey >> 31) & 0xffffffffu);
       bj = P.straight ? hi : hi - bx;
     }
+    ExactOut* out = W.outs + p;
     out->score = gbv;
     out->bx = bx;
     out->bj = bj;
-    out->nops = *err ? 0xffffffffu : 0;
+    out->nops = __hip_atomic_load(W.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0xffffffffu : 0;
   }
 }
 
-__global__ void __launch_bounds__(1024) sw_exact_kernel(const ExactPair* pairs, ExactOut* outs, uint32_t n,
-                                                        int match, int miss, int gap) {
-  __shared__ uint32_t prog[16];
-  __shared__ uint32_t red[16 * 3];
-  __shared__ uint32_t err;
-  const uint32_t p = blockIdx.x;
-  if (p >= n) return;
-  if (threadIdx.x == 0) err = 0;
-  const ExactPair P = pairs[p];
-  if (P.dirs)
-    exact_pair<true>(P, outs + p, match, miss, gap, prog, red, &err);
-  else
-    exact_pair<false>(P, outs + p, match, miss, gap, prog, red, &err);
-}
-
-// Traceback walker: one lane per pair follows the direction bits from the best cell until H reaches 0
+// Traceback walker: one WAVE per pair follows the direction bits from the best cell until H reaches 0
 // (rust/src/algorithm/mod.rs:663-664 `if score == 0 return`) or an edge (:650).  ops[] receives, last
 // alignment column first: 0 = (q[x-1], t[j-1]), 1 = (q[x-1], '-'), 2 = ('-', t[j-1]).
+// The walk itself is serial, so what matters is the latency of one step: the wave stages a window of the
+// direction words (8 blocks of 16 steps x 256 rows of the current strip = 8 KB, coalesced), the strip's query
+// symbols and the matching target range in LDS and walks inside it with wave-uniform (scalar) state; within a
+// strip the step index k = j - 1 + lane(row) never increases along the walk, so a window is left only downwards
+// or when the path crosses into the strip above.  Ops are collected one per lane and flushed 64 at a time.
+constexpr uint32_t WKB = 8;  // 16-step blocks per window
 __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, ExactOut* outs, uint32_t n,
                                                      int match, int miss, int gap) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ uint32_t wdir[WKB * SH];  // [block][row of the strip]
+  __shared__ uint32_t wq[SH];
+  __shared__ uint32_t wt[WKB * 16 + 64];
+  const uint32_t p = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
   if (p >= n) return;
   const ExactPair P = pairs[p];
   if (!P.dirs || !P.ops) return;
-  if (outs[p].nops == 0xffffffffu) return;  // the fill kernel reported a pipeline time-out
-  int H = outs[p].score;
-  uint32_t x = outs[p].bx, j = outs[p].bj;
-  uint32_t nops = 0;
+  if (outs[p].nops == 0xffffffffu) return;  // the fill kernel reported a hand-over time-out
+  int H = __builtin_amdgcn_readfirstlane(outs[p].score);
+  const uint32_t bx = (uint32_t)__builtin_amdgcn_readfirstlane((int)outs[p].bx);
+  const uint32_t bj = (uint32_t)__builtin_amdgcn_readfirstlane((int)outs[p].bj);
   const uint32_t cap = P.Q + P.T;
-  while (H > 0 && x > 0 && j > 0 && nops < cap) {
-    const uint32_t i = x - 1;
-    const uint32_t strip = i / SH, within = i % SH, lane = within / RPL, r = within % RPL;
-    const uint32_t k = (j - 1) + lane;
-    const uint32_t w = P.dirs[((size_t)(strip * P.nkb + (k >> 4)) * RPL + r) * 64 + lane];
-    const uint32_t code = (w >> (2 * (15 - (k & 15)))) & 3u;
-    uint8_t op;
-    if (code & 1u) {
-      H -= (P.q[x - 1] == P.t[j - 1]) ? match : miss;
-      x--;
-      j--;
-      op = 0;
-    } else if (code & 2u) {
-      H -= gap;
-      x--;
-      op = 1;
-    } else {
-      H -= gap;
-      j--;
-      op = 2;
+  uint32_t nops = 0, myop = 0;
+  if (H > 0 && bx > 0 && bj > 0) {
+    // wave-uniform walk state: strip, row inside the strip, target index j - 1
+    uint32_t strip = (bx - 1) / SH;
+    int within = (int)((bx - 1) % SH);
+    int jm1 = (int)bj - 1;
+    bool go = true;
+    while (go) {
+      // ---- stage a window: blocks [wbase, wtop] of this strip; all loads in flight before the first LDS write
+      const uint32_t ktop = (uint32_t)jm1 + ((uint32_t)within >> 2);
+      const uint32_t wtop = ktop >> 4;
+      const uint32_t wbase = wtop >= WKB - 1 ? wtop - (WKB - 1) : 0;
+      const uint32_t nb = wtop - wbase + 1;
+      const int tbase = (int)(wbase * 16) - 63;  // wt[i] = t[tbase + i]
+      __syncthreads();  // (one wave: orders the LDS reads of the old window before the overwrite)
+      {
+        const uint32_t* src = P.dirs + ((size_t)(strip * P.nkb + wbase) * RPL) * 64 + lane;
+        uint32_t v[WKB * RPL];
+#pragma unroll
+        for (uint32_t u = 0; u < WKB * RPL; u++) v[u] = (u < nb * RPL) ? src[(size_t)u * 64] : 0u;
+        uint32_t qv[SH / 64], tv[(WKB * 16 + 64) / 64];
+#pragma unroll
+        for (uint32_t u = 0; u < SH / 64; u++) {
+          const uint32_t row = strip * SH + u * 64 + lane;
+          qv[u] = row < P.Q ? P.q[row] : 0x10000u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < (WKB * 16 + 64) / 64; u++) {
+          const int tj = tbase + (int)(u * 64 + lane);
+          tv[u] = (tj >= 0 && (uint32_t)tj < P.T) ? P.t[tj] : 0x20000u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < WKB * RPL; u++)  // word u = (block u / RPL, row lane * RPL + u % RPL)
+          wdir[(u / RPL) * SH + lane * RPL + (u % RPL)] = v[u];
+#pragma unroll
+        for (uint32_t u = 0; u < SH / 64; u++) wq[u * 64 + lane] = qv[u];
+#pragma unroll
+        for (uint32_t u = 0; u < (WKB * 16 + 64) / 64; u++) wt[u * 64 + lane] = tv[u];
+      }
+      __syncthreads();
+      // ---- walk inside the window.  Every lane carries the same state in VECTOR registers and the step is
+      // branch-free (a lone wave issues one instruction per 4 cycles whatever its type, and a taken branch
+      // costs several): three LDS reads, a dozen VALU operations and one loop branch per step.
+      const int wlo = (int)(wbase * 16);  // smallest step index covered
+      int vH = H, vwithin = within, vjm1 = jm1;
+      // keep the compiler from proving the state wave-uniform and turning the step into scalar code + branches
+      asm volatile("" : "+v"(vH), "+v"(vwithin), "+v"(vjm1));
+      for (;;) {
+        const int k = vjm1 + (vwithin >> 2);
+        if (k < wlo) break;  // window exhausted (same strip)
+        const uint32_t w = wdir[(((uint32_t)k >> 4) - wbase) * SH + (uint32_t)vwithin];
+        const uint32_t qsym = wq[vwithin];
+        const uint32_t tsym = wt[vjm1 - tbase];
+        const uint32_t code = w >> ((~(uint32_t)k & 15u) * 2);
+        const bool diag = code & 1u;
+        const bool up = !diag && (code & 2u);
+        const int sub = (qsym == tsym) ? match : miss;
+        vH -= diag ? sub : gap;
+        vwithin -= (diag || up) ? 1 : 0;
+        vjm1 -= up ? 0 : 1;
+        const uint32_t op = diag ? 0u : (up ? 1u : 2u);
+        if (lane == (nops & 63u)) myop = op;
+        nops++;
+        if ((nops & 63u) == 0) P.ops[nops - 64 + lane] = (uint8_t)myop;
+        if (vH <= 0 || vjm1 < 0 || vwithin < 0 || nops >= cap) break;
+      }
+      H = __builtin_amdgcn_readfirstlane(vH);
+      within = __builtin_amdgcn_readfirstlane(vwithin);
+      jm1 = __builtin_amdgcn_readfirstlane(vjm1);
+      if (H <= 0 || jm1 < 0 || nops >= cap) {
+        go = false;
+      } else if (within < 0) {  // into the strip above (or off the top edge)
+        if (strip == 0) go = false;
+        strip--;
+        within = SH - 1;
+      }
     }
-    P.ops[nops++] = op;
   }
-  outs[p].nops = nops;
+  if (lane < (nops & 63u)) P.ops[(nops & ~63u) + lane] = (uint8_t)myop;
+  if (lane == 0) outs[p].nops = nops;
 }
 
 }  // namespace
 
-hipError_t launch_exact(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, int waves, Scoring sc,
-                        hipStream_t stream) {
-  if (n_pairs == 0) return hipSuccess;
-  if (waves < 1) waves = 1;
-  if (waves > 16) waves = 16;
-  hipLaunchKernelGGL(sw_exact_kernel, dim3(n_pairs), dim3(64 * waves), 0, stream, d_pairs, d_outs, n_pairs,
-                     sc.match, sc.miss, sc.gap);
+hipError_t launch_exact(const ExactWork& w, Scoring sc, hipStream_t stream) {
+  if (w.n_units == 0) return hipSuccess;
+  hipLaunchKernelGGL(sw_exact_kernel, dim3(w.n_units), dim3(64), 0, stream, w, sc.match, sc.miss, sc.gap);
   return hipGetLastError();
 }
 
 hipError_t launch_walk(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, Scoring sc,
                        hipStream_t stream) {
   if (n_pairs == 0) return hipSuccess;
-  hipLaunchKernelGGL(sw_walk_kernel, dim3((n_pairs + 63) / 64), dim3(64), 0, stream, d_pairs, d_outs, n_pairs,
+  hipLaunchKernelGGL(sw_walk_kernel, dim3(n_pairs), dim3(64), 0, stream, d_pairs, d_outs, n_pairs,
                      sc.match, sc.miss, sc.gap);
   return hipGetLastError();
 }

@@ -28,11 +28,14 @@ struct ExactPair {
   uint32_t T0;        // last column computed for row x == 1
   uint32_t phaseQp;   // != 0: ring path with T < Qp, two-phase discovery order, value = Qp
   uint32_t straight;  // != 0: tie order of find_alignment_sequential_straight (smallest j, then x)
-  int32_t* bnd;       // scratch: nstrips rows of bnd_pitch ints (row s = bottom row of strip s)
+  int32_t* bnd;       // scratch: nstrips rows of bnd_pitch ints (row s = bottom row of strip s), zeroed:
+                      // bit 31 of a word = published (sw_exact.hip)
   uint32_t bnd_pitch;
   uint32_t* dirs;     // nullptr: score + best cell only.  Else 2 bits per cell (layout in sw_exact.hip)
   uint32_t nkb;       // 16-step blocks per strip
   uint8_t* ops;       // traceback ops written by the walker (capacity Q + T)
+  uint32_t first_unit; // ticket of this pair's strip 0 (tickets are drawn in (pair, strip) order)
+  uint32_t n_units;    // max(number of strips, 1)
 };
 struct ExactOut {
   int32_t score;  // H of the best cell (0: no hit)
@@ -44,15 +47,31 @@ constexpr int kExactRPL = 4;             // rows per lane
 constexpr int kExactSH = 64 * kExactRPL; // rows per strip
 
 // steps per strip (multiple of 64) for a pair whose widest row has `maxcol` columns
-inline uint32_t exact_nsteps(uint32_t maxcol) { return maxcol == 0 ? 0 : ((maxcol + 63 + 63) / 64) * 64; }
-inline uint32_t exact_nstrips(uint32_t Q) { return (Q + kExactSH - 1) / kExactSH; }
+__host__ __device__ inline uint32_t exact_nsteps(uint32_t maxcol) { return maxcol == 0 ? 0 : ((maxcol + 63 + 63) / 64) * 64; }
+__host__ __device__ inline uint32_t exact_nstrips(uint32_t Q) { return (Q + kExactSH - 1) / kExactSH; }
 inline size_t exact_dir_words(uint32_t Q, uint32_t maxcol) {
   return (size_t)exact_nstrips(Q) * (exact_nsteps(maxcol) / 16) * kExactRPL * 64;
 }
 
-// `waves`: wavefronts per pair (1..16); strips of a pair are spread over them
-hipError_t launch_exact(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, int waves, Scoring sc,
-                        hipStream_t stream);
+// best cell of one strip (the last strip of a pair to finish combines them)
+struct ExactRec {
+  int32_t score;
+  uint32_t key_lo, key_hi;  // order_key of sw_exact.hip
+  uint32_t pad_;
+};
+// One launch = n_units waves, one 256-row strip each, spread over the whole GPU.
+struct ExactWork {
+  const ExactPair* pairs;
+  ExactOut* outs;
+  const uint32_t* unit_pair;  // per ticket: index of its pair
+  uint32_t n_units;
+  uint32_t n_pairs;
+  ExactRec* recs;       // per ticket
+  uint32_t* pair_done;  // per pair: strips finished (zeroed)
+  uint32_t* ticket;     // work counter (zeroed)
+  uint32_t* err;        // != 0: a hand-over wait timed out (zeroed)
+};
+hipError_t launch_exact(const ExactWork& w, Scoring sc, hipStream_t stream);
 hipError_t launch_walk(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, Scoring sc,
                        hipStream_t stream);
 

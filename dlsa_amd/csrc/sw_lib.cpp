@@ -70,6 +70,7 @@ struct Context {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   DevBuf sym, pairs, outs, dirs, bnd, ops;            // exact path scratch
+  DevBuf xunits, xctl, xrecs;                          // exact path: ticket table, control words, strip records
   DevBuf qwords, slot_scores, gbound, ticket, prog;    // score path scratch
   sw_kernel_stats stats{};
   size_t scratch_budget = (size_t)8 << 30;
@@ -204,7 +205,7 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
   std::vector<ExactPair> hp(n);
   std::vector<size_t> qoff(n), toff(n);
   size_t dir_words = 0, bnd_ints = 0, ops_bytes = 0;
-  uint32_t max_strips = 1;
+  std::vector<uint32_t> unit_pair;
   for (size_t i = 0; i < n; i++) {
     const PairSpec& s = specs[begin + i];
     qoff[i] = add_seq(s.q, s.Q);
@@ -220,10 +221,13 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
     const uint32_t maxcol = std::max(pp.Tlim, pp.T0);
     e.bnd_pitch = maxcol + 2;
     e.nkb = exact_nsteps(maxcol) / 16;
+    e.n_units = std::max<uint32_t>(exact_nstrips(s.Q), 1);
+    if (unit_pair.size() + e.n_units > 0x7fffff00ull) return fail(SW_E_ARG, "too many strips in one submission");
+    e.first_unit = (uint32_t)unit_pair.size();
+    unit_pair.insert(unit_pair.end(), e.n_units, (uint32_t)i);
     // temporarily store offsets in the pointer fields
     e.bnd = (int32_t*)(uintptr_t)bnd_ints;
-    bnd_ints += (size_t)std::max<uint32_t>(exact_nstrips(s.Q), 1) * e.bnd_pitch;
-    max_strips = std::max(max_strips, exact_nstrips(s.Q));
+    bnd_ints += (size_t)e.n_units * e.bnd_pitch;
     if (want_trace) {
       e.dirs = (uint32_t*)(uintptr_t)(dir_words + 1);  // +1 so that offset 0 is not nullptr
       dir_words += exact_dir_words(s.Q, maxcol);
@@ -234,11 +238,17 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
       e.ops = nullptr;
     }
   }
+  const size_t n_units = unit_pair.size();
+  // control words: [0] ticket, [32] err, [64 ..) per-pair done counters
+  const size_t ctl_words = 64 + n;
   int rc;
   if ((rc = c.sym.ensure(std::max<size_t>(pool.size() * 2, 16)))) return rc;
   if ((rc = c.pairs.ensure(n * sizeof(ExactPair)))) return rc;
   if ((rc = c.outs.ensure(n * sizeof(ExactOut)))) return rc;
   if ((rc = c.bnd.ensure(std::max<size_t>(bnd_ints * 4, 16)))) return rc;
+  if ((rc = c.xunits.ensure(n_units * 4))) return rc;
+  if ((rc = c.xctl.ensure(ctl_words * 4))) return rc;
+  if ((rc = c.xrecs.ensure(n_units * sizeof(ExactRec)))) return rc;
   if (want_trace) {
     if ((rc = c.dirs.ensure(std::max<size_t>(dir_words * 4, 16)))) return rc;
     if ((rc = c.ops.ensure(std::max<size_t>(ops_bytes, 16)))) return rc;
@@ -255,11 +265,22 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
   }
   if (!pool.empty()) HIPCK(hipMemcpyAsync(c.sym.p, pool.data(), pool.size() * 2, hipMemcpyHostToDevice, c.stream));
   HIPCK(hipMemcpyAsync(c.pairs.p, hp.data(), n * sizeof(ExactPair), hipMemcpyHostToDevice, c.stream));
+  HIPCK(hipMemcpyAsync(c.xunits.p, unit_pair.data(), n_units * 4, hipMemcpyHostToDevice, c.stream));
+  HIPCK(hipMemsetAsync(c.xctl.p, 0, ctl_words * 4, c.stream));
+  // strip boundary rows: a word is "published" when its bit 31 is set (sw_exact.hip), so they start at zero
+  HIPCK(hipMemsetAsync(c.bnd.p, 0, std::max<size_t>(bnd_ints * 4, 16), c.stream));
   HIPCK(hipEventRecord(c.ev2, c.stream));
-  // waves per pair: enough for the longest query of the chunk, fewer when many pairs fill the GPU anyway
-  int waves = (int)std::min<uint32_t>(max_strips, 16);
-  if (n >= (size_t)c.cus * 8) waves = std::min(waves, 4);
-  HIPCK(launch_exact((const ExactPair*)c.pairs.p, (ExactOut*)c.outs.p, (uint32_t)n, waves, sc, c.stream));
+  ExactWork w{};
+  w.pairs = (const ExactPair*)c.pairs.p;
+  w.outs = (ExactOut*)c.outs.p;
+  w.unit_pair = (const uint32_t*)c.xunits.p;
+  w.n_units = (uint32_t)n_units;
+  w.n_pairs = (uint32_t)n;
+  w.ticket = (uint32_t*)c.xctl.p;
+  w.err = (uint32_t*)c.xctl.p + 32;
+  w.pair_done = (uint32_t*)c.xctl.p + 64;
+  w.recs = (ExactRec*)c.xrecs.p;
+  HIPCK(launch_exact(w, sc, c.stream));
   if (want_trace) HIPCK(launch_walk((const ExactPair*)c.pairs.p, (ExactOut*)c.outs.p, (uint32_t)n, sc, c.stream));
   HIPCK(hipEventRecord(c.ev3, c.stream));
   std::vector<ExactOut> ho(n);

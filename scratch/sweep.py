@@ -37,9 +37,15 @@ def pair_case(name, Q, T, mutate=None):
     else:
         t = q.copy()[:T]; idx = rng.random(T) < mutate; t[idx] = np.frombuffer(b"ATCG", dtype=np.uint8)[rng.integers(0, 4, size=int(idx.sum()))]
     sc = dlsa_amd.AlignmentScore(2, -1, -1)
-    t0 = time.perf_counter(); r = bridge.align_batch([q.tobytes()], [t.tobytes()], sc, 0); dt = time.perf_counter() - t0
+    best = 1e9
+    for _ in range(2):
+        k0 = bridge.last_stats()["exact_kernel_ms"]
+        t0 = time.perf_counter(); r = bridge.align_batch([q.tobytes()], [t.tobytes()], sc, 0); dt = time.perf_counter() - t0
+        best = min(best, dt)
+        kms = bridge.last_stats()["exact_kernel_ms"] - k0
+    dt = best
     r0 = r[0]
-    print(json.dumps({"case": name, "Q": Q, "T": T, "s": round(dt, 3), "gcups": round(Q * T / dt / 1e9, 2),
+    print(json.dumps({"case": name, "Q": Q, "T": T, "s": round(dt, 4), "gcups": round(Q * T / dt / 1e9, 2), "kernels_ms": round(kms, 3),
                       "score": None if r0 is None else r0.score, "alen": None if r0 is None else len(r0.query)}), flush=True)
 
 which = sys.argv[1:]

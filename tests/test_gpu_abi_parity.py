@@ -179,3 +179,42 @@ def test_align_batch_matches_single_calls(oracle):
         for q, t, g in zip(qs, ts, res):
             e = oracle.align(func, q, t, -1, 2, -1)
             assert (g.query, g.target, g.score, g.max_x, g.max_y) == (e["q"], e["t"], e["score"], e["max_x"], e["max_y"])
+
+
+def _verify_alignment(q, t, res, sc):
+    """master/utils/verify.py:24-48 restated: the aligned strings re-derive the score and end at max_x/max_y."""
+    gap, match, miss = sc
+    s = 0
+    for a, b in zip(res.query, res.target):
+        s += gap if (a == "-" or b == "-") else (match if a == b else miss)
+    assert s == res.score32
+    qa, ta = res.query.replace("-", ""), res.target.replace("-", "")
+    assert q[res.max_x + 1 - len(qa):res.max_x + 1] == qa
+    assert t[res.max_y + 1 - len(ta):res.max_y + 1] == ta
+
+
+def test_long_pairs_strips_chained_across_the_gpu(oracle):
+    """Several thousand rows = tens of 256-row strips, each on its own wave somewhere on the GPU; compared with
+    the clean int32 model (the line-by-line restatement's full matrix would be GBs here).  Scores above 32767
+    are the documented int32 divergence: Result.score holds the low 16 bits, sw_result_score32 the value."""
+    import dlsa_amd
+    rng = random.Random(99)
+    sc = (-1, 2, -1)
+    cases = []
+    q = _rnd(rng, 6000)
+    cases.append((q, _rnd(rng, 7000)))                                   # unrelated: low score, long matrix
+    mut = "".join(c if rng.random() > 0.05 else rng.choice("ACGT") for c in q[500:5500])
+    cases.append((q, _rnd(rng, 300) + mut + _rnd(rng, 900)))             # 5 kb hit, score < 32767
+    q2 = _rnd(rng, 20000)
+    mut2 = "".join(c if rng.random() > 0.03 else rng.choice("ACGT") for c in q2)
+    cases.append((q2, mut2[:19990]))                                      # score > 32767: int32
+    cases.append((_rnd(rng, 9000), _rnd(rng, 64 * 40)))                   # T % 64 == 0 quirk, full path
+    cases.append((_rnd(rng, 700), _rnd(rng, 30000)))                      # ring path, long target
+    for q, t in cases:
+        exp = oracle.clean_align(0, q, t, *sc)
+        res, err = dlsa_amd.find_rust_alignment_simd_low_mem(q, t, dlsa_amd.AlignmentScore(sc[1], sc[2], sc[0]))
+        assert err is None, err
+        assert (res.score32, res.max_x, res.max_y) == (exp["score"], exp["max_x"], exp["max_y"]), (len(q), len(t))
+        assert (res.query, res.target) == (exp["q"], exp["t"])
+        assert res.score == exp["score"] & 0xFFFF
+        _verify_alignment(q, t, res, sc)
