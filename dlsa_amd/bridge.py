@@ -110,6 +110,9 @@ def lib():
     L.sw_db_residues.restype = C.c_uint64
     L.sw_db_search_topk.argtypes = [C.c_void_p, C.c_char_p, CScores, C.c_int, C.POINTER(CHit), C.POINTER(C.c_int)]
     L.sw_db_search_topk.restype = C.c_int
+    L.sw_db_search_topk_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t, CScores, C.c_int,
+                                          C.POINTER(CHit), C.POINTER(C.c_int)]
+    L.sw_db_search_topk_batch.restype = C.c_int
     L.sw_db_scores.argtypes = [C.c_void_p, C.c_char_p, CScores, C.POINTER(C.c_int32)]
     L.sw_db_scores.restype = C.c_int
     L.sw_hits_free.argtypes = [C.POINTER(CHit), C.c_int]
@@ -225,6 +228,12 @@ class Database:
             raise SwHipError(f"sw_db_scores failed ({rc}): {last_error()}")
         return out
 
+    @staticmethod
+    def _hit(h):
+        return dict(target_index=int(h.target_index), score=int(h.score), length=int(h.length),
+                    max_x=int(h.max_x), max_y=int(h.max_y),
+                    query_aln=C.string_at(h.query_aln).decode(), target_aln=C.string_at(h.target_aln).decode())
+
     def search_topk(self, query, score, k):
         L = lib()
         hits = (CHit * max(k, 1))()
@@ -232,13 +241,24 @@ class Database:
         rc = L.sw_db_search_topk(self._h, _b(query), score.c(), k, hits, C.byref(nh))
         if rc != 0:
             raise SwHipError(f"sw_db_search_topk failed ({rc}): {last_error()}")
-        out = []
-        for i in range(nh.value):
-            h = hits[i]
-            out.append(dict(target_index=int(h.target_index), score=int(h.score), length=int(h.length),
-                            max_x=int(h.max_x), max_y=int(h.max_y),
-                            query_aln=C.string_at(h.query_aln).decode(), target_aln=C.string_at(h.target_aln).decode()))
+        out = [self._hit(hits[i]) for i in range(nh.value)]
         L.sw_hits_free(hits, nh.value)
+        return out
+
+    def search_topk_batch(self, queries, score, k):
+        """sw_db_search_topk_batch: one list of hits per query."""
+        L = lib()
+        n = len(queries)
+        qs = (C.c_char_p * max(n, 1))(*[_b(q) for q in queries])
+        hits = (CHit * max(n * k, 1))()
+        nh = (C.c_int * max(n, 1))()
+        rc = L.sw_db_search_topk_batch(self._h, qs, n, score.c(), k, hits, nh)
+        if rc != 0:
+            raise SwHipError(f"sw_db_search_topk_batch failed ({rc}): {last_error()}")
+        out = []
+        for q in range(n):
+            out.append([self._hit(hits[q * k + i]) for i in range(nh[q])])
+            L.sw_hits_free(C.cast(C.byref(hits, q * k * C.sizeof(CHit)), C.POINTER(CHit)), nh[q])
         return out
 
 

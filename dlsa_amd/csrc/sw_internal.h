@@ -123,4 +123,26 @@ int score_waves_per_group();
 int score_workgroups_per_cu();
 uint32_t score_queue_depth();  // units a workgroup may have in flight
 
+
+// ---- device-side top-k selection over the per-slot scores (sw_topk.hip) --------------------------------------
+enum { kSelRerun = 0, kSelCand = 1, kSelTie = 2, kSelThresh = 3, kSelAbove = 4, kSelWords = 8 };
+struct SelectParams {
+  const int32_t* slot_scores;   // per slot, as the score kernel left them
+  const uint32_t* lens;         // per slot: target length (0: padding)
+  const uint32_t* slot_target;  // per slot: database index
+  uint32_t n_slots;
+  uint32_t Q;
+  int match;
+  uint32_t k;
+  uint32_t* hist;      // 32768 bins (zeroed)
+  uint32_t* counters;  // kSelWords words (zeroed)
+  uint32_t* rerun;     // slots the exact kernel must re-score
+  uint32_t rerun_cap;
+  uint32_t* cand;      // (score, database index) pairs above the threshold score
+  uint32_t cand_cap;
+  uint32_t* tie;       // ... at the threshold score
+  uint32_t tie_cap;
+};
+hipError_t launch_select(const SelectParams& p, hipStream_t stream);
+
 }  // namespace swhip

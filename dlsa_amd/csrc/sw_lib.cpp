@@ -71,6 +71,7 @@ struct Context {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   DevBuf sym, pairs, outs, dirs, bnd, ops;            // exact path scratch
   DevBuf xunits, xctl, xrecs;                          // exact path: ticket table, control words, strip records
+  DevBuf sel_hist, sel_ctr, sel_rerun, sel_cand, sel_tie;  // device-side top-k selection
   DevBuf qwords, slot_scores, gbound, ticket, prog;    // score path scratch
   sw_kernel_stats stats{};
   size_t scratch_budget = (size_t)8 << 30;
@@ -589,6 +590,8 @@ struct sw_db {
   std::vector<ScoreGroup> groups;
   uint32_t* d_words = nullptr;
   uint32_t* d_lens = nullptr;
+  uint32_t* d_slot_target = nullptr;  // per slot: database index (UINT32_MAX: padding)
+  uint64_t packed_residues = 0;       // residues of the packed targets
   ScoreGroup* d_groups = nullptr;
   uint32_t* d_elem_group = nullptr;  // per strip of the stream: its group
   uint32_t n_elems = 0;              // strips in the stream
@@ -615,6 +618,7 @@ void db_release(sw_db* db) {
   if (!db) return;
   if (db->d_words) (void)hipFree(db->d_words);
   if (db->d_lens) (void)hipFree(db->d_lens);
+  if (db->d_slot_target) (void)hipFree(db->d_slot_target);
   if (db->d_groups) (void)hipFree(db->d_groups);
   if (db->d_elem_group) (void)hipFree(db->d_elem_group);
   if (db->d_units) (void)hipFree(db->d_units);
@@ -700,6 +704,7 @@ sw_db* db_build(std::string&& flat, std::vector<uint64_t>&& off) {
       uint32_t len = (uint32_t)(db->off[ti + 1] - db->off[ti]);
       db->slot_target[k] = ti;
       lens[k] = len;
+      db->packed_residues += len;
       maxlen = std::max(maxlen, len);
     }
     if (total_strips > 0xfff00000ull) {
@@ -744,6 +749,7 @@ sw_db* db_build(std::string&& flat, std::vector<uint64_t>&& off) {
   });
   if (ngroups) {
     if (hipMalloc(&db->d_words, words.size() * 4) != hipSuccess || hipMalloc(&db->d_lens, lens.size() * 4) != hipSuccess ||
+        hipMalloc(&db->d_slot_target, lens.size() * 4) != hipSuccess ||
         hipMalloc(&db->d_groups, ngroups * sizeof(ScoreGroup)) != hipSuccess ||
         hipMalloc(&db->d_elem_group, elem_group.size() * 4) != hipSuccess) {
       db_release(db);
@@ -752,6 +758,7 @@ sw_db* db_build(std::string&& flat, std::vector<uint64_t>&& off) {
     }
     if (hipMemcpy(db->d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(db->d_lens, lens.data(), lens.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(db->d_slot_target, db->slot_target.data(), lens.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(db->d_groups, db->groups.data(), ngroups * sizeof(ScoreGroup), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(db->d_elem_group, elem_group.data(), elem_group.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
       db_release(db);
@@ -827,116 +834,244 @@ bool fast_domain(Scoring sc) {
   return sc.match > 0 && sc.miss < 0 && sc.gap < 0 && sc.match <= 16384 && sc.miss >= -16384 && sc.gap >= -16384;
 }
 
+// Launches the score kernel for one query over the packed part of the database (asynchronous, on the library's
+// stream; ev0/ev1 bracket the kernel).  The per-slot maxima are left in c.slot_scores.
+int score_pass_locked(sw_db* db, const QueryPrep& qp, Scoring sc) {
+  Context& c = g_ctx;
+  const uint32_t Q = (uint32_t)qp.d.sym.size();
+  const uint32_t nblk = (Q + kScoreB - 1) / kScoreB;
+  const size_t Qpad = (size_t)nblk * kScoreB;
+  const uint32_t W = (uint32_t)score_waves_per_group();
+  const uint32_t max_wg = (uint32_t)c.cus * (uint32_t)score_workgroups_per_cu();
+  // interleave: a unit should be handed out about 40 blocks after the unit it continues, i.e. when that
+  // one's last wave is publishing; max_wg workgroups draw max_wg tickets per (nblk + drain) blocks
+  const uint32_t S = std::min<uint32_t>(1024, std::max<uint32_t>(8, max_wg * 40 / (nblk + 16)));
+  // boundary ring: a workgroup has at most 1 + queue depth units in flight, fewer when a unit is long
+  const uint32_t ahead = std::min<uint32_t>(score_queue_depth(), 48 / nblk + 1);
+  const uint32_t ring_slots = S + max_wg * (1 + ahead) + 8;
+  if (db->units_S != S || db->units_R != ring_slots || !db->d_units) {
+    std::vector<ScoreUnit> units;
+    build_units(db, W, S, ring_slots, units);
+    if (db->d_units) (void)hipFree(db->d_units);
+    db->d_units = nullptr;
+    if (hipMalloc(&db->d_units, std::max<size_t>(units.size(), 1) * sizeof(ScoreUnit)) != hipSuccess)
+      return fail(SW_E_NOMEM, "hipMalloc failed for the unit table");
+    HIPCK(hipMemcpy(db->d_units, units.data(), units.size() * sizeof(ScoreUnit), hipMemcpyHostToDevice));
+    db->n_units = (uint32_t)units.size();
+    db->units_S = S;
+    db->units_R = ring_slots;
+  }
+  const int nwg = (int)std::min<uint32_t>(db->n_units, max_wg);
+  const size_t gb_stride = Qpad * 64;
+  int rc;
+  if ((rc = c.qwords.ensure(qp.qwords.size() * 4))) return rc;
+  if ((rc = c.slot_scores.ensure(db->slot_target.size() * 4))) return rc;
+  if ((rc = c.gbound.ensure((size_t)ring_slots * gb_stride * 4))) return rc;
+  if ((rc = c.ticket.ensure(256))) return rc;
+  if ((rc = c.prog.ensure(std::max<size_t>((size_t)db->n_units * 8, 16)))) return rc;
+  HIPCK(hipMemcpyAsync(c.qwords.p, qp.qwords.data(), qp.qwords.size() * 4, hipMemcpyHostToDevice, c.stream));
+  HIPCK(hipMemsetAsync(c.ticket.p, 0, 256, c.stream));
+  HIPCK(hipMemsetAsync(c.prog.p, 0, std::max<size_t>((size_t)db->n_units * 8, 16), c.stream));
+  HIPCK(hipMemsetAsync(c.slot_scores.p, 0, db->slot_target.size() * 4, c.stream));
+  ScoreParams p{};
+  p.words = db->d_words;
+  p.groups = db->d_groups;
+  p.lens = db->d_lens;
+  p.qwords = (const uint32_t*)c.qwords.p;
+  p.Q = Q;
+  p.elem_group = db->d_elem_group;
+  p.units = db->d_units;
+  p.n_units = db->n_units;
+  p.slot_scores = (int32_t*)c.slot_scores.p;
+  p.gbound = (uint32_t*)c.gbound.p;
+  p.gbound_stride = gb_stride;
+  p.ring_slots = ring_slots;
+  p.prog = (uint32_t*)c.prog.p;
+  p.ticket = (uint32_t*)c.ticket.p;
+  p.err = (uint32_t*)c.ticket.p + 32;
+  p.match = sc.match;
+  p.miss = sc.miss;
+  p.gap = sc.gap;
+  HIPCK(hipEventRecord(c.ev0, c.stream));
+  HIPCK(launch_score(p, nwg, c.stream));
+  HIPCK(hipEventRecord(c.ev1, c.stream));
+  return SW_OK;
+}
+
+// after the stream has been synchronised: error word + kernel time of the last score pass
+int score_pass_finish_locked(sw_db* db, uint32_t Q, uint32_t kerr) {
+  Context& c = g_ctx;
+  if (kerr) return fail(SW_E_HIP, "score kernel: a dependency wait timed out");
+  float ms = 0;
+  HIPCK(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+  c.stats.score_kernel_ms += ms;
+  c.stats.score_launches += 1;
+  c.stats.score_cells += (uint64_t)Q * db->packed_residues;
+  return SW_OK;
+}
+
+// A packed target's int16 score is final unless one of these holds (the same rules run on the
+// device in sw_topk.hip):
+bool needs_exact(uint32_t T, int32_t s, uint32_t Q, uint32_t Qp, Scoring sc) {
+  const bool full = (uint64_t)T < 2ull * Q;
+  if (s >= 32767) return true;                                                    // int16 saturation -> int32 re-run
+  if (!full && T < Qp) return true;                                               // ring path with T < Qp (quirk Q2)
+  if (full && T % 64 == 0 && roundup64(T) >= Qp && s < sc.match) return true;     // only H(1,T) can score
+  return false;
+}
+
+// exact (int32, score only) re-run of a list of database targets
+int rescore_locked(sw_db* db, const QueryPrep& qp, Scoring sc, const std::vector<uint32_t>& rerun,
+                   std::vector<int32_t>& out) {
+  out.assign(rerun.size(), 0);
+  if (rerun.empty()) return SW_OK;
+  const uint32_t Q = (uint32_t)qp.d.sym.size();
+  std::vector<PairSpec> specs(rerun.size());
+  std::vector<std::vector<uint16_t>> tsym(rerun.size());
+  for (size_t k = 0; k < rerun.size(); k++) {
+    uint32_t ti = rerun[k];
+    const unsigned char* s = (const unsigned char*)db->flat.data() + db->off[ti];
+    uint32_t T = (uint32_t)(db->off[ti + 1] - db->off[ti]);
+    tsym[k].assign(s, s + T);
+    specs[k] = PairSpec{qp.d.sym.data(), Q, tsym[k].data(), T, SW_PATH_LOW_MEMORY};
+  }
+  std::vector<PairOut> po(rerun.size());
+  int rc = run_exact(specs.data(), specs.size(), sc, false, po.data());
+  if (rc) return rc;
+  for (size_t k = 0; k < rerun.size(); k++) out[k] = po[k].score;
+  g_ctx.stats.rerun_pairs += (uint32_t)rerun.size();
+  return SW_OK;
+}
+
+bool fast_path(const sw_db* db, const QueryPrep& qp, Scoring sc) {
+  return qp.acgt && fast_domain(sc) && !qp.d.sym.empty() && !db->groups.empty();
+}
+
 // scores of every database sequence against one query, reference-exact (low_memory semantics)
-int db_scores_locked(sw_db* db, const QueryPrep& qp, Scoring sc, std::vector<int32_t>& scores,
-                     std::vector<std::vector<uint16_t>>& tsym_cache) {
+int db_scores_locked(sw_db* db, const QueryPrep& qp, Scoring sc, std::vector<int32_t>& scores) {
   Context& c = g_ctx;
   const uint32_t Q = (uint32_t)qp.d.sym.size();
   scores.assign(db->n, 0);
   std::vector<uint32_t> rerun(db->generic);
-  const bool fast = qp.acgt && fast_domain(sc) && Q > 0 && !db->groups.empty();
-  if (!fast) {
+  if (!fast_path(db, qp, sc)) {
     rerun.resize(db->n);
     std::iota(rerun.begin(), rerun.end(), 0u);
   } else {
-    const uint32_t nblk = (Q + kScoreB - 1) / kScoreB;
-    const size_t Qpad = (size_t)nblk * kScoreB;
-    const uint32_t W = (uint32_t)score_waves_per_group();
-    const uint32_t max_wg = (uint32_t)c.cus * (uint32_t)score_workgroups_per_cu();
-    // interleave: a unit should be handed out about 40 blocks after the unit it continues, i.e. when that
-    // one's last wave is publishing; max_wg workgroups draw max_wg tickets per (nblk + drain) blocks
-    const uint32_t S = std::min<uint32_t>(1024, std::max<uint32_t>(8, max_wg * 40 / (nblk + 16)));
-    // boundary ring: a workgroup has at most 1 + queue depth units in flight, fewer when a unit is long
-    const uint32_t ahead = std::min<uint32_t>(score_queue_depth(), 48 / nblk + 1);
-    const uint32_t ring_slots = S + max_wg * (1 + ahead) + 8;
-    if (db->units_S != S || db->units_R != ring_slots || !db->d_units) {
-      std::vector<ScoreUnit> units;
-      build_units(db, W, S, ring_slots, units);
-      if (db->d_units) (void)hipFree(db->d_units);
-      db->d_units = nullptr;
-      if (hipMalloc(&db->d_units, std::max<size_t>(units.size(), 1) * sizeof(ScoreUnit)) != hipSuccess)
-        return fail(SW_E_NOMEM, "hipMalloc failed for the unit table");
-      HIPCK(hipMemcpy(db->d_units, units.data(), units.size() * sizeof(ScoreUnit), hipMemcpyHostToDevice));
-      db->n_units = (uint32_t)units.size();
-      db->units_S = S;
-      db->units_R = ring_slots;
-    }
-    const int nwg = (int)std::min<uint32_t>(db->n_units, max_wg);
-    const size_t gb_stride = Qpad * 64;
-    int rc;
-    if ((rc = c.qwords.ensure(qp.qwords.size() * 4))) return rc;
-    if ((rc = c.slot_scores.ensure(db->slot_target.size() * 4))) return rc;
-    if ((rc = c.gbound.ensure((size_t)ring_slots * gb_stride * 4))) return rc;
-    if ((rc = c.ticket.ensure(256))) return rc;
-    if ((rc = c.prog.ensure(std::max<size_t>((size_t)db->n_units * 8, 16)))) return rc;
-    HIPCK(hipMemcpyAsync(c.qwords.p, qp.qwords.data(), qp.qwords.size() * 4, hipMemcpyHostToDevice, c.stream));
-    HIPCK(hipMemsetAsync(c.ticket.p, 0, 256, c.stream));
-    HIPCK(hipMemsetAsync(c.prog.p, 0, std::max<size_t>((size_t)db->n_units * 8, 16), c.stream));
-    HIPCK(hipMemsetAsync(c.slot_scores.p, 0, db->slot_target.size() * 4, c.stream));
-    ScoreParams p{};
-    p.words = db->d_words;
-    p.groups = db->d_groups;
-    p.lens = db->d_lens;
-    p.qwords = (const uint32_t*)c.qwords.p;
-    p.Q = Q;
-    p.elem_group = db->d_elem_group;
-    p.units = db->d_units;
-    p.n_units = db->n_units;
-    p.slot_scores = (int32_t*)c.slot_scores.p;
-    p.gbound = (uint32_t*)c.gbound.p;
-    p.gbound_stride = gb_stride;
-    p.ring_slots = ring_slots;
-    p.prog = (uint32_t*)c.prog.p;
-    p.ticket = (uint32_t*)c.ticket.p;
-    p.err = (uint32_t*)c.ticket.p + 32;
-    p.match = sc.match;
-    p.miss = sc.miss;
-    p.gap = sc.gap;
-    HIPCK(hipEventRecord(c.ev0, c.stream));
-    HIPCK(launch_score(p, nwg, c.stream));
-    HIPCK(hipEventRecord(c.ev1, c.stream));
+    int rc = score_pass_locked(db, qp, sc);
+    if (rc) return rc;
     std::vector<int32_t> slot(db->slot_target.size());
     HIPCK(hipMemcpyAsync(slot.data(), c.slot_scores.p, slot.size() * 4, hipMemcpyDeviceToHost, c.stream));
     uint32_t kerr = 0;
     HIPCK(hipMemcpyAsync(&kerr, (uint32_t*)c.ticket.p + 32, 4, hipMemcpyDeviceToHost, c.stream));
     HIPCK(hipStreamSynchronize(c.stream));
-    if (kerr) return fail(SW_E_HIP, "score kernel: a dependency wait timed out");
-    float ms = 0;
-    HIPCK(hipEventElapsedTime(&ms, c.ev0, c.ev1));
-    c.stats.score_kernel_ms += ms;
-    c.stats.score_launches += 1;
+    if ((rc = score_pass_finish_locked(db, Q, kerr))) return rc;
     const uint32_t Qp = roundup64(Q);
     for (size_t k = 0; k < slot.size(); k++) {
       uint32_t ti = db->slot_target[k];
       if (ti == UINT32_MAX) continue;
       const uint32_t T = (uint32_t)(db->off[ti + 1] - db->off[ti]);
-      c.stats.score_cells += (uint64_t)Q * T;
-      const int32_t s = slot[k];
-      const bool full = (uint64_t)T < 2ull * Q;
-      bool need = false;
-      if (s >= 32767) need = true;                                   // int16 saturation -> int32 re-run
-      if (!full && T < Qp) need = true;                              // ring path with T < Qp (quirk Q2)
-      if (full && T % 64 == 0 && roundup64(T) >= Qp && s < sc.match) need = true;  // only H(1,T) can score
-      if (need) rerun.push_back(ti);
-      else scores[ti] = s;
+      if (needs_exact(T, slot[k], Q, Qp, sc)) rerun.push_back(ti);
+      else scores[ti] = slot[k];
     }
   }
-  if (!rerun.empty()) {
-    std::vector<PairSpec> specs(rerun.size());
-    tsym_cache.resize(rerun.size());
-    for (size_t k = 0; k < rerun.size(); k++) {
-      uint32_t ti = rerun[k];
-      const unsigned char* s = (const unsigned char*)db->flat.data() + db->off[ti];
-      uint32_t T = (uint32_t)(db->off[ti + 1] - db->off[ti]);
-      tsym_cache[k].assign(s, s + T);
-      specs[k] = PairSpec{qp.d.sym.data(), Q, tsym_cache[k].data(), T, SW_PATH_LOW_MEMORY};
-    }
-    std::vector<PairOut> po(rerun.size());
-    int rc = run_exact(specs.data(), specs.size(), sc, false, po.data());
+  std::vector<int32_t> rs;
+  int rc = rescore_locked(db, qp, sc, rerun, rs);
+  if (rc) return rc;
+  for (size_t k = 0; k < rerun.size(); k++) scores[rerun[k]] = rs[k];
+  return SW_OK;
+}
+
+struct TopEntry {
+  int32_t score;
+  uint32_t target;
+};
+inline bool top_before(const TopEntry& a, const TopEntry& b) {
+  // score descending, then database index ascending (declared replacement of the reference's arrival-order
+  // ties, cli/__main__.py:171)
+  return a.score != b.score ? a.score > b.score : a.target < b.target;
+}
+
+bool g_host_topk = [] {
+  const char* e = getenv("SW_HIP_TOPK");
+  return e && std::string(e) == "host";
+}();
+constexpr uint32_t kTieCap = 65536;
+
+// The k best (score, target) of the database for one query.  Selection runs on the device (sw_topk.hip): only
+// the candidates and the slots that need an exact re-run are downloaded.  Falls back to the full download when
+// the tie list overflows (e.g. a database where every target scores the same) or with SW_HIP_TOPK=host.
+int db_topk_locked(sw_db* db, const QueryPrep& qp, Scoring sc, size_t k, std::vector<TopEntry>& top) {
+  Context& c = g_ctx;
+  top.clear();
+  k = std::min<size_t>(k, db->n);
+  if (k == 0) return SW_OK;
+  const uint32_t Q = (uint32_t)qp.d.sym.size();
+  bool device_done = false;
+  std::vector<TopEntry> pool;
+  if (fast_path(db, qp, sc) && !g_host_topk && k <= 4096) {
+    int rc = score_pass_locked(db, qp, sc);
     if (rc) return rc;
-    for (size_t k = 0; k < rerun.size(); k++) scores[rerun[k]] = po[k].score;
-    c.stats.rerun_pairs += (uint32_t)rerun.size();
+    const uint32_t n_slots = (uint32_t)db->slot_target.size();
+    if ((rc = c.sel_hist.ensure(32768 * 4))) return rc;
+    if ((rc = c.sel_ctr.ensure(kSelWords * 4))) return rc;
+    if ((rc = c.sel_rerun.ensure((size_t)n_slots * 4))) return rc;
+    if ((rc = c.sel_cand.ensure(std::max<size_t>(k, 16) * 8))) return rc;
+    if ((rc = c.sel_tie.ensure((size_t)kTieCap * 8))) return rc;
+    HIPCK(hipMemsetAsync(c.sel_hist.p, 0, 32768 * 4, c.stream));
+    HIPCK(hipMemsetAsync(c.sel_ctr.p, 0, kSelWords * 4, c.stream));
+    SelectParams sp{};
+    sp.slot_scores = (const int32_t*)c.slot_scores.p;
+    sp.lens = db->d_lens;
+    sp.slot_target = db->d_slot_target;
+    sp.n_slots = n_slots;
+    sp.Q = Q;
+    sp.match = sc.match;
+    sp.k = (uint32_t)k;
+    sp.hist = (uint32_t*)c.sel_hist.p;
+    sp.counters = (uint32_t*)c.sel_ctr.p;
+    sp.rerun = (uint32_t*)c.sel_rerun.p;
+    sp.rerun_cap = n_slots;
+    sp.cand = (uint32_t*)c.sel_cand.p;
+    sp.cand_cap = (uint32_t)std::max<size_t>(k, 16);
+    sp.tie = (uint32_t*)c.sel_tie.p;
+    sp.tie_cap = kTieCap;
+    HIPCK(launch_select(sp, c.stream));
+    uint32_t ctr[kSelWords] = {0};
+    uint32_t kerr = 0;
+    HIPCK(hipMemcpyAsync(ctr, c.sel_ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, c.stream));
+    HIPCK(hipMemcpyAsync(&kerr, (uint32_t*)c.ticket.p + 32, 4, hipMemcpyDeviceToHost, c.stream));
+    HIPCK(hipStreamSynchronize(c.stream));
+    if ((rc = score_pass_finish_locked(db, Q, kerr))) return rc;
+    if (ctr[kSelTie] <= kTieCap && ctr[kSelCand] <= sp.cand_cap && ctr[kSelRerun] <= n_slots) {
+      std::vector<uint32_t> cand(2 * (size_t)ctr[kSelCand]), tie(2 * (size_t)ctr[kSelTie]), rr(ctr[kSelRerun]);
+      if (!cand.empty()) HIPCK(hipMemcpyAsync(cand.data(), c.sel_cand.p, cand.size() * 4, hipMemcpyDeviceToHost, c.stream));
+      if (!tie.empty()) HIPCK(hipMemcpyAsync(tie.data(), c.sel_tie.p, tie.size() * 4, hipMemcpyDeviceToHost, c.stream));
+      if (!rr.empty()) HIPCK(hipMemcpyAsync(rr.data(), c.sel_rerun.p, rr.size() * 4, hipMemcpyDeviceToHost, c.stream));
+      HIPCK(hipStreamSynchronize(c.stream));
+      for (size_t i = 0; i < cand.size(); i += 2) pool.push_back(TopEntry{(int32_t)cand[i], cand[i + 1]});
+      for (size_t i = 0; i < tie.size(); i += 2) pool.push_back(TopEntry{(int32_t)tie[i], tie[i + 1]});
+      std::vector<uint32_t> rerun(db->generic);
+      for (uint32_t slot : rr) rerun.push_back(db->slot_target[slot]);
+      std::vector<int32_t> rs;
+      if ((rc = rescore_locked(db, qp, sc, rerun, rs))) return rc;
+      for (size_t i = 0; i < rerun.size(); i++) pool.push_back(TopEntry{rs[i], rerun[i]});
+      device_done = true;
+    } else {
+      // undo the accounting of the pass we are about to repeat through the host path
+      c.stats.score_launches -= 1;
+      c.stats.score_cells -= (uint64_t)Q * db->packed_residues;
+    }
   }
+  if (!device_done) {
+    std::vector<int32_t> scores;
+    int rc = db_scores_locked(db, qp, sc, scores);
+    if (rc) return rc;
+    pool.resize(db->n);
+    for (uint32_t i = 0; i < db->n; i++) pool[i] = TopEntry{scores[i], i};
+  }
+  const size_t kk = std::min(k, pool.size());
+  std::partial_sort(pool.begin(), pool.begin() + kk, pool.end(), top_before);
+  top.assign(pool.begin(), pool.begin() + kk);
   return SW_OK;
 }
 
@@ -1023,75 +1158,90 @@ int sw_db_scores(sw_db* db, const char* query, AlignmentScores as, int32_t* scor
   if (!prep_query(query, qp)) return fail(SW_E_ARG, "query is not valid UTF-8");
   const Scoring sc = to_scoring(as);
   std::vector<int32_t> scores;
-  std::vector<std::vector<uint16_t>> cache;
   std::lock_guard<std::mutex> lk(g_ctx.mu);
   int rc = ctx_init_locked(-1);
   if (rc) return rc;
   g_ctx.stats = sw_kernel_stats{};
-  rc = db_scores_locked(db, qp, sc, scores, cache);
+  rc = db_scores_locked(db, qp, sc, scores);
   if (rc) return rc;
   memcpy(scores_out, scores.data(), scores.size() * sizeof(int32_t));
   return SW_OK;
 }
 
-int sw_db_search_topk(sw_db* db, const char* query, AlignmentScores as, int k, sw_hit* hits, int* n_hits) {
-  if (!db || !query || !hits || !n_hits || k < 0) return fail(SW_E_ARG, "bad argument");
-  *n_hits = 0;
-  QueryPrep qp;
-  if (!prep_query(query, qp)) return fail(SW_E_ARG, "query is not valid UTF-8");
+int sw_db_search_topk_batch(sw_db* db, const char* const* queries, size_t n_queries, AlignmentScores as, int k,
+                            sw_hit* hits, int* n_hits) {
+  if (!db || (!queries && n_queries) || !hits || !n_hits || k < 0) return fail(SW_E_ARG, "bad argument");
+  for (size_t q = 0; q < n_queries; q++) n_hits[q] = 0;
+  if (n_queries == 0 || k == 0) return SW_OK;
+  std::vector<QueryPrep> qps(n_queries);
+  for (size_t q = 0; q < n_queries; q++)
+    if (!queries[q] || !prep_query(queries[q], qps[q]))
+      return fail(SW_E_ARG, "query " + std::to_string(q) + " is not valid UTF-8");
   const Scoring sc = to_scoring(as);
-  std::vector<int32_t> scores;
-  std::vector<std::vector<uint16_t>> cache;
-  std::vector<PairOut> po;
-  std::vector<uint32_t> order;
+  std::vector<std::vector<TopEntry>> tops(n_queries);
+  std::vector<PairSpec> specs;
   std::vector<std::vector<uint16_t>> tsym;
+  std::vector<PairOut> po;
   {
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     int rc = ctx_init_locked(-1);
     if (rc) return rc;
     g_ctx.stats = sw_kernel_stats{};
-    rc = db_scores_locked(db, qp, sc, scores, cache);
-    if (rc) return rc;
-    // top-k: score descending, then database index ascending (declared replacement of the reference's
-    // arrival-order ties, cli/__main__.py:171)
-    const size_t kk = std::min<size_t>((size_t)k, db->n);
-    order.resize(db->n);
-    std::iota(order.begin(), order.end(), 0u);
-    auto cmp = [&](uint32_t a, uint32_t b) { return scores[a] != scores[b] ? scores[a] > scores[b] : a < b; };
-    std::partial_sort(order.begin(), order.begin() + kk, order.end(), cmp);
-    order.resize(kk);
-    std::vector<PairSpec> specs(kk);
-    tsym.resize(kk);
-    for (size_t i = 0; i < kk; i++) {
-      uint32_t ti = order[i];
-      const unsigned char* s = (const unsigned char*)db->flat.data() + db->off[ti];
-      uint32_t T = (uint32_t)(db->off[ti + 1] - db->off[ti]);
-      tsym[i].assign(s, s + T);
-      specs[i] = PairSpec{qp.d.sym.data(), (uint32_t)qp.d.sym.size(), tsym[i].data(), T, SW_PATH_LOW_MEMORY};
+    // score pass + selection per query, then ONE exact submission (end cell + traceback) for all reported hits
+    size_t total = 0;
+    for (size_t q = 0; q < n_queries; q++) {
+      rc = db_topk_locked(db, qps[q], sc, (size_t)k, tops[q]);
+      if (rc) return rc;
+      total += tops[q].size();
     }
-    po.resize(kk);
-    rc = run_exact(specs.data(), kk, sc, true, po.data());
+    specs.reserve(total);
+    tsym.resize(total);
+    size_t at = 0;
+    for (size_t q = 0; q < n_queries; q++)
+      for (const TopEntry& e : tops[q]) {
+        const unsigned char* s = (const unsigned char*)db->flat.data() + db->off[e.target];
+        const uint32_t T = (uint32_t)(db->off[e.target + 1] - db->off[e.target]);
+        tsym[at].assign(s, s + T);
+        specs.push_back(PairSpec{qps[q].d.sym.data(), (uint32_t)qps[q].d.sym.size(), tsym[at].data(), T, SW_PATH_LOW_MEMORY});
+        at++;
+      }
+    po.resize(total);
+    rc = run_exact(specs.data(), total, sc, true, po.data());
     if (rc) return rc;
   }
   std::string qa, ta;
   std::vector<uint32_t> tcps;
-  for (size_t i = 0; i < order.size(); i++) {
-    tcps.assign(tsym[i].begin(), tsym[i].end());
-    build_alignment(qp.d.cps, tcps, po[i], qa, ta);
-    if (po[i].score != scores[order[i]])
-      return fail(SW_E_HIP, "internal: score kernel and exact kernel disagree on target " + std::to_string(order[i]) + " (" +
-                                std::to_string(scores[order[i]]) + " vs " + std::to_string(po[i].score) + ")");
-    sw_hit& h = hits[i];
-    h.target_index = order[i];
-    h.score = po[i].score;
-    h.length = (uint32_t)qa.size();
-    h.max_x = (uint64_t)po[i].bx - 1;
-    h.max_y = (uint64_t)po[i].bj - 1;
-    h.query_aln = dup_string(qa);
-    h.target_aln = dup_string(ta);
+  size_t at = 0;
+  for (size_t q = 0; q < n_queries; q++) {
+    for (size_t i = 0; i < tops[q].size(); i++, at++) {
+      const TopEntry& e = tops[q][i];
+      tcps.assign(tsym[at].begin(), tsym[at].end());
+      build_alignment(qps[q].d.cps, tcps, po[at], qa, ta);
+      if (po[at].score != e.score) {
+        for (size_t r = 0; r < n_queries; r++) {
+          sw_hits_free(hits + r * (size_t)k, n_hits[r]);
+          n_hits[r] = 0;
+        }
+        return fail(SW_E_HIP, "internal: score kernel and exact kernel disagree on target " + std::to_string(e.target) +
+                                  " (" + std::to_string(e.score) + " vs " + std::to_string(po[at].score) + ")");
+      }
+      sw_hit& h = hits[q * (size_t)k + i];
+      h.target_index = e.target;
+      h.score = po[at].score;
+      h.length = (uint32_t)qa.size();
+      h.max_x = (uint64_t)po[at].bx - 1;
+      h.max_y = (uint64_t)po[at].bj - 1;
+      h.query_aln = dup_string(qa);
+      h.target_aln = dup_string(ta);
+      n_hits[q] = (int)i + 1;
+    }
   }
-  *n_hits = (int)order.size();
   return SW_OK;
+}
+
+int sw_db_search_topk(sw_db* db, const char* query, AlignmentScores as, int k, sw_hit* hits, int* n_hits) {
+  if (!query) return fail(SW_E_ARG, "bad argument");
+  return sw_db_search_topk_batch(db, &query, 1, as, k, hits, n_hits);
 }
 
 void sw_hits_free(sw_hit* hits, int n_hits) {

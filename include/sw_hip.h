@@ -85,6 +85,13 @@ struct sw_hit {
  * the k best hits with full alignments.  *n_hits <= k.  Exact for every reported field. */
 int sw_db_search_topk(sw_db *db, const char *query, struct AlignmentScores scores, int k,
                       struct sw_hit *hits, int *n_hits);
+/* The same for n_queries queries in one call: what a work package of the reference holds (many queries against
+ * the same targets, internal/worker/worker_impl.go:108-168 loops over its pairs).  hits has room for
+ * n_queries * k records, query q's hits start at hits[q * k]; n_hits has n_queries entries.  The score pass and
+ * the on-device top-k selection run per query; end cells and tracebacks of all reported hits go to the GPU in
+ * one submission. */
+int sw_db_search_topk_batch(sw_db *db, const char *const *queries, size_t n_queries, struct AlignmentScores scores,
+                            int k, struct sw_hit *hits, int *n_hits);
 /* All scores (int32, database order), for tests and for schedulers that want every pair. */
 int sw_db_scores(sw_db *db, const char *query, struct AlignmentScores scores, int32_t *scores_out);
 void sw_hits_free(struct sw_hit *hits, int n_hits);

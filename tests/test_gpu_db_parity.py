@@ -123,3 +123,81 @@ def test_c1_shape_1kb_query_vs_1000_targets(oracle):
     targets = [_rnd(rng, rng.randint(900, 1100)) for _ in range(1000)]
     targets[123] = targets[123][:300] + q[200:700] + targets[123][300:500]
     _run(oracle, q, targets, (-1, 2, -1), k=5)
+
+
+def _expected_hits(oracle, q, targets, sc, k):
+    exp = _oracle_all(oracle, q, targets, sc)
+    return [(i, exp[i]["score"], exp[i]["max_x"], exp[i]["max_y"], exp[i]["q"], exp[i]["t"]) for i in _topk(exp, k)]
+
+
+def _as_tuples(hits):
+    return [(h["target_index"], h["score"], h["max_x"], h["max_y"], h["query_aln"], h["target_aln"]) for h in hits]
+
+
+def test_batch_of_queries_matches_single_searches(oracle):
+    """sw_db_search_topk_batch (a work package: many queries, one database) == one sw_db_search_topk per query ==
+    the oracle; queries of different lengths, one of them outside the packed fast path (non-ACGT)."""
+    import dlsa_amd
+    from dlsa_amd import bridge
+    rng = random.Random(5)
+    sc = (-1, 2, -1)
+    s = dlsa_amd.AlignmentScore(sc[1], sc[2], sc[0])
+    targets = [_rnd(rng, rng.randint(30, 400)) for _ in range(400)]
+    queries = [_rnd(rng, n) for n in (150, 37, 260, 64)] + ["ACGTNNACGTACGGT" * 4, ""]
+    targets[11] = targets[11][:20] + queries[0][10:140] + targets[11][20:]
+    targets[12] = queries[2][100:230]
+    db = bridge.Database(seqs=targets)
+    try:
+        got = db.search_topk_batch(queries, s, 4)
+        assert len(got) == len(queries)
+        for q, hits in zip(queries, got):
+            assert _as_tuples(hits) == _expected_hits(oracle, q, targets, sc, 4), q[:20]
+            assert _as_tuples(hits) == _as_tuples(db.search_topk(q, s, 4))
+        assert db.search_topk_batch([], s, 4) == []
+    finally:
+        db.close()
+
+
+def test_device_topk_ties_reruns_and_k_larger_than_hits(oracle):
+    """The on-device selection (histogram threshold + candidate/tie lists) must give exactly the order the host
+    rule defines: score descending, then database index ascending -- with many equal scores, with re-run targets
+    (saturated, quirk lengths, non-ACGT) competing for the top, and with k above the number of targets."""
+    import dlsa_amd
+    from dlsa_amd import bridge
+    rng = random.Random(6)
+    sc = (-1, 2, -1)
+    s = dlsa_amd.AlignmentScore(sc[1], sc[2], sc[0])
+    q = _rnd(rng, 200)
+    base = [_rnd(rng, 90) for _ in range(6)]
+    targets = [base[i % 6] for i in range(600)]            # 100 copies of 6 sequences: ties everywhere
+    targets[301] = q[50:150]                                 # a clear winner
+    targets[302] = "N" + q[40:160]                           # non-ACGT -> exact path, second
+    targets[5] = _rnd(rng, 64 * 3)                           # T % 64 == 0 on the full path (quirk)
+    targets[77] = _rnd(rng, 450)                             # ring path (T >= 2Q)
+    db = bridge.Database(seqs=targets)
+    try:
+        for k in (1, 5, 40, 700):
+            assert _as_tuples(db.search_topk(q, s, k)) == _expected_hits(oracle, q, targets, sc, k), k
+    finally:
+        db.close()
+
+
+def test_device_topk_tie_list_overflow_falls_back(oracle):
+    """More than 65536 targets with the threshold score: the tie list overflows and the library must fall back to
+    the full download -- same answer (the smallest database indices among the ties)."""
+    import dlsa_amd
+    from dlsa_amd import bridge
+    sc = (-1, 2, -1)
+    s = dlsa_amd.AlignmentScore(sc[1], sc[2], sc[0])
+    q = "ACGTTGCAAGGCTTAACCGG"
+    n = 70000
+    targets = ["TTGCAAGG"] * n
+    targets[12345] = "ACGTTGCAAGGCTT"
+    db = bridge.Database(seqs=targets)
+    try:
+        hits = db.search_topk(q, s, 4)
+        assert [h["target_index"] for h in hits] == [12345, 0, 1, 2]
+        e = oracle.align("lowmem", q, targets[0], *sc)
+        assert (hits[1]["score"], hits[1]["query_aln"], hits[1]["target_aln"]) == (e["score"], e["q"], e["t"])
+    finally:
+        db.close()
