@@ -38,6 +38,22 @@ class CHit(C.Structure):  # include/sw_hip.h struct sw_hit
                 ("target_aln", C.c_void_p)]
 
 
+class CWorkPair(C.Structure):  # include/sw_worker.h struct sw_work_pair
+    _fields_ = [("query", C.c_uint32), ("target", C.c_uint32)]
+
+
+class CWorkPackage(C.Structure):  # include/sw_worker.h struct sw_work_package
+    _fields_ = [("sequences", C.POINTER(C.c_char_p)), ("n_sequences", C.c_uint64),
+                ("pairs", C.POINTER(CWorkPair)), ("n_pairs", C.c_uint64),
+                ("match_score", C.c_int32), ("mismatch_penalty", C.c_int32), ("gap_penalty", C.c_int32)]
+
+
+class CAlignmentDetail(C.Structure):  # include/sw_worker.h struct sw_alignment_detail
+    _fields_ = [("query", C.c_uint32), ("target", C.c_uint32), ("query_alignment", C.c_void_p),
+                ("target_alignment", C.c_void_p), ("length", C.c_int64), ("score", C.c_int64),
+                ("max_x", C.c_int64), ("max_y", C.c_int64), ("score32", C.c_int32), ("entry", C.c_int32)]
+
+
 class CStats(C.Structure):  # include/sw_hip.h struct sw_kernel_stats
     _fields_ = [("score_kernel_ms", C.c_double), ("exact_kernel_ms", C.c_double), ("score_cells", C.c_uint64),
                 ("exact_cells", C.c_uint64), ("score_launches", C.c_uint32), ("rerun_pairs", C.c_uint32)]
@@ -122,6 +138,27 @@ def lib():
     L.sw_hip_benchmark_cups.restype = C.c_float
     L.sw_hip_path_params.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
     L.sw_hip_path_params.restype = C.c_int
+    # include/sw_worker.h
+    L.sw_execute_work.argtypes = [C.POINTER(CWorkPackage), C.POINTER(CAlignmentDetail)]
+    L.sw_execute_work.restype = C.c_int
+    L.sw_alignment_details_free.argtypes = [C.POINTER(CAlignmentDetail), C.c_uint64]
+    L.sw_alignment_details_free.restype = None
+    L.sw_benchmark_rust.argtypes = [C.c_double, C.c_int, C.c_int]
+    L.sw_benchmark_rust.restype = C.c_float
+    L.sw_fasta_parse.argtypes = [C.c_char_p]
+    L.sw_fasta_parse.restype = C.c_void_p
+    L.sw_fasta_count.argtypes = [C.c_void_p]
+    L.sw_fasta_count.restype = C.c_uint64
+    L.sw_fasta_id.argtypes = [C.c_void_p, C.c_uint64]
+    L.sw_fasta_id.restype = C.c_char_p
+    L.sw_fasta_sequence.argtypes = [C.c_void_p, C.c_uint64]
+    L.sw_fasta_sequence.restype = C.c_char_p
+    L.sw_fasta_free.argtypes = [C.c_void_p]
+    L.sw_fasta_free.restype = None
+    L.sw_db_from_fasta.argtypes = [C.c_void_p]
+    L.sw_db_from_fasta.restype = C.c_void_p
+    L.sw_write_query_results.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(CHit), C.c_int]
+    L.sw_write_query_results.restype = C.c_int
     _lib = L
     return L
 
@@ -188,9 +225,12 @@ def align_batch(queries, targets, score, path=0):
 class Database:
     """A resident target database (sw_db_*)."""
 
-    def __init__(self, seqs=None, flat=None, offsets=None):
+    def __init__(self, seqs=None, flat=None, offsets=None, fasta=None):
         L = lib()
-        if seqs is not None:
+        if fasta is not None:  # a Fasta object (dlsa_amd.worker)
+            self._h = L.sw_db_from_fasta(fasta._h)
+            n = len(fasta)
+        elif seqs is not None:
             bs = [_b(s) for s in seqs]
             flat = b"".join(bs)
             offs = [0]

@@ -11,6 +11,9 @@
 
 namespace swhip {
 
+// records the calling thread's last error message (sw_hip_last_error)
+void set_last_error(const std::string& msg);
+
 // ---- scoring ------------------------------------------------------------------------------------------
 struct Scoring {
   int match, miss, gap;  // as the reference sees them: match > 0, miss < 0, gap < 0 on the fast paths

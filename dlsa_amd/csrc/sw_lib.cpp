@@ -21,7 +21,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "../../include/sw_hip.h"
+#include "../../include/sw_worker.h"
 #include "sw_internal.h"
 
 using namespace swhip;
@@ -34,6 +34,9 @@ int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
 }
+}  // namespace
+void swhip::set_last_error(const std::string& msg) { g_err = msg; }
+namespace {
 #define HIPCK(expr)                                                                                  \
   do {                                                                                               \
     hipError_t e__ = (expr);                                                                         \
@@ -1113,36 +1116,17 @@ sw_db* sw_db_create(const char* flat, const uint64_t* offsets, uint64_t n) {
 }
 
 sw_db* sw_db_load_fasta(const char* path) {
-  if (!path) {
-    fail(SW_E_ARG, "null path");
-    return nullptr;
-  }
-  std::ifstream in(path, std::ios::binary);
-  if (!in) {
-    fail(SW_E_ARG, std::string("cannot open ") + path);
-    return nullptr;
-  }
-  // cli/__main__.py:19-34: split on '>', first line is the header, the remaining lines are concatenated
-  std::string flat, line;
-  std::vector<uint64_t> off;
-  bool have = false;
-  while (std::getline(in, line)) {
-    while (!line.empty() && (line.back() == '\r' || line.back() == '\n')) line.pop_back();
-    if (!line.empty() && line[0] == '>') {
-      off.push_back(flat.size());
-      have = true;
-    } else if (have) {
-      flat += line;
-    }
-  }
-  if (!have) {
+  // cli/__main__.py:19-34 through the one parser of sw_worker.cpp
+  sw_fasta* f = sw_fasta_parse(path);
+  if (!f) return nullptr;
+  if (sw_fasta_count(f) == 0) {
+    sw_fasta_free(f);
     fail(SW_E_ARG, "no FASTA records");
     return nullptr;
   }
-  off.push_back(flat.size());
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  if (ctx_init_locked(-1)) return nullptr;
-  return db_build(std::move(flat), std::move(off));
+  sw_db* db = sw_db_from_fasta(f);
+  sw_fasta_free(f);
+  return db;
 }
 
 void sw_db_free(sw_db* db) {

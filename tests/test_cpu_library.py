@@ -19,7 +19,7 @@ def L():
 
 def _declared_symbols():
     names = set()
-    for h in ("sw.h", "sw_hip.h"):
+    for h in ("sw.h", "sw_hip.h", "sw_worker.h"):
         src = open(os.path.join(ROOT, "include", h)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
         for m in re.finditer(r"\b([a-z_][a-z0-9_]*)\s*\(", src):
