@@ -186,11 +186,13 @@ struct PairSpec {
 struct PairOut {
   int32_t score = 0;
   uint32_t bx = 0, bj = 0;
-  std::vector<uint8_t> ops;  // last alignment column first
+  size_t ops_off = 0;  // traceback ops (last alignment column first) at arena[ops_off .. ops_off + nops)
+  uint32_t nops = 0;
 };
 
 // Runs pairs [begin, end) in one submission.  Caller holds the context mutex.
-int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc, bool want_trace, PairOut* outs) {
+int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc, bool want_trace, PairOut* outs,
+                    std::vector<uint8_t>* arena) {
   Context& c = g_ctx;
   const size_t n = end - begin;
   if (n == 0) return SW_OK;
@@ -295,10 +297,12 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
   float ms = 0;
   HIPCK(hipEventElapsedTime(&ms, c.ev2, c.ev3));
   c.stats.exact_kernel_ms += ms;
-  std::vector<uint8_t> hops;
+  size_t arena_base = 0;
   if (want_trace && ops_bytes) {
-    // copy only what the walkers wrote
-    hops.resize(ops_bytes);
+    // copy only what the walkers wrote, straight into the caller's arena
+    arena_base = arena->size();
+    arena->resize(arena_base + ops_bytes);
+    uint8_t* hops = arena->data() + arena_base;
     size_t lo = 0;
     while (lo < n) {  // coalesce into a few large copies: ops buffers are contiguous per pair
       size_t hi = lo;
@@ -310,7 +314,7 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
         endb = s0 + ho[hi].nops;
         hi++;
       }
-      if (endb > start) HIPCK(hipMemcpyAsync(hops.data() + start, (uint8_t*)c.ops.p + start, endb - start, hipMemcpyDeviceToHost, c.stream));
+      if (endb > start) HIPCK(hipMemcpyAsync(hops + start, (uint8_t*)c.ops.p + start, endb - start, hipMemcpyDeviceToHost, c.stream));
       lo = hi;
     }
     HIPCK(hipStreamSynchronize(c.stream));
@@ -322,14 +326,15 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
     o.bj = ho[i].bj;
     c.stats.exact_cells += (uint64_t)specs[begin + i].Q * specs[begin + i].T;
     if (want_trace && ho[i].nops) {
-      size_t s0 = (uint8_t*)hp[i].ops - (uint8_t*)c.ops.p;
-      o.ops.assign(hops.begin() + s0, hops.begin() + s0 + ho[i].nops);
+      o.ops_off = arena_base + (size_t)((uint8_t*)hp[i].ops - (uint8_t*)c.ops.p);
+      o.nops = ho[i].nops;
     }
   }
   return SW_OK;
 }
 
-int run_exact(const PairSpec* specs, size_t n, Scoring sc, bool want_trace, PairOut* outs) {
+int run_exact(const PairSpec* specs, size_t n, Scoring sc, bool want_trace, PairOut* outs,
+              std::vector<uint8_t>* arena = nullptr) {
   Context& c = g_ctx;
   size_t begin = 0;
   while (begin < n) {
@@ -343,7 +348,7 @@ int run_exact(const PairSpec* specs, size_t n, Scoring sc, bool want_trace, Pair
       bytes += b;
       end++;
     }
-    int rc = run_exact_chunk(specs, begin, end, sc, want_trace, outs);
+    int rc = run_exact_chunk(specs, begin, end, sc, want_trace, outs, arena);
     if (rc) return rc;
     begin = end;
   }
@@ -368,40 +373,93 @@ char* dup_string(const std::string& s) {
   return p;
 }
 
-// Builds the two aligned strings from the walker's ops (rust/src/algorithm/mod.rs:677-706: the recursion
-// pushes after returning, so the first cell visited is the LAST column).
-void build_alignment(const std::vector<uint32_t>& q, const std::vector<uint32_t>& t, const PairOut& o,
-                     std::string& qa, std::string& ta) {
-  qa.clear();
-  ta.clear();
-  uint32_t x = o.bx, j = o.bj;
-  // positions at the start of the alignment
+// A sequence as the algorithm sees it: Unicode scalars truncated to u16 (`*x as u16`,
+// rust/src/algorithm/mod.rs:78,224).  Pure-ASCII input (the normal case: DNA) never materialises code points.
+struct Decoded {
+  const char* src = nullptr;   // borrowed
+  bool ascii = true;
+  std::vector<uint32_t> cps;   // only when !ascii: for re-encoding the alignment
+  std::vector<uint16_t> sym;
+  uint32_t cp(size_t i) const { return ascii ? (uint32_t)(unsigned char)src[i] : cps[i]; }
+};
+bool decode(const char* s, size_t n, Decoded& d) {
+  d.src = s;
+  unsigned char any = 0;
+  for (size_t i = 0; i < n; i++) any |= (unsigned char)s[i];
+  d.sym.resize(n);
+  if (!(any & 0x80)) {
+    d.ascii = true;
+    for (size_t i = 0; i < n; i++) d.sym[i] = (unsigned char)s[i];
+    return true;
+  }
+  d.ascii = false;
+  std::string tmp(s, n);  // decode_utf8 wants a terminator
+  if (!decode_utf8(tmp.c_str(), d.cps)) return false;
+  d.sym.resize(d.cps.size());
+  for (size_t i = 0; i < d.cps.size(); i++) d.sym[i] = (uint16_t)d.cps[i];
+  return true;
+}
+bool decode(const char* s, Decoded& d) { return s && decode(s, strlen(s), d); }
+
+// Builds the two aligned strings (malloc'ed, NUL-terminated) from the walker's ops (rust/src/algorithm/mod.rs:
+// 677-706: the recursion pushes after returning, so the first cell visited is the LAST column).
+bool build_alignment(const Decoded& q, const Decoded& t, const PairOut& o, const uint8_t* ops, char** qa_out,
+                     char** ta_out, size_t* qa_len) {
   uint32_t nx = 0, nj = 0;
-  for (uint8_t op : o.ops) {
-    if (op == 0) { nx++; nj++; }
-    else if (op == 1) nx++;
-    else nj++;
+  for (uint32_t k = 0; k < o.nops; k++) {
+    nx += ops[k] != 2;
+    nj += ops[k] != 1;
   }
-  uint32_t cx = x - nx, cj = j - nj;  // 0-based index of the first aligned symbol
-  for (size_t k = o.ops.size(); k-- > 0;) {
-    uint8_t op = o.ops[k];
-    if (op == 0) { encode_utf8(q[cx++], qa); encode_utf8(t[cj++], ta); }
-    else if (op == 1) { encode_utf8(q[cx++], qa); ta.push_back('-'); }
-    else { qa.push_back('-'); encode_utf8(t[cj++], ta); }
+  uint32_t cx = o.bx - nx, cj = o.bj - nj;  // 0-based index of the first aligned symbol
+  if (q.ascii && t.ascii) {
+    char* qa = (char*)malloc((size_t)o.nops + 1);
+    char* ta = (char*)malloc((size_t)o.nops + 1);
+    if (!qa || !ta) {
+      free(qa);
+      free(ta);
+      return false;
+    }
+    size_t w = 0;
+    for (uint32_t k = o.nops; k-- > 0; w++) {
+      const uint8_t op = ops[k];
+      qa[w] = op == 2 ? '-' : q.src[cx++];
+      ta[w] = op == 1 ? '-' : t.src[cj++];
+    }
+    qa[w] = ta[w] = 0;
+    *qa_out = qa;
+    *ta_out = ta;
+    *qa_len = w;
+    return true;
   }
+  std::string qa, ta;
+  for (uint32_t k = o.nops; k-- > 0;) {
+    const uint8_t op = ops[k];
+    if (op == 2) qa.push_back('-');
+    else encode_utf8(q.cp(cx++), qa);
+    if (op == 1) ta.push_back('-');
+    else encode_utf8(t.cp(cj++), ta);
+  }
+  *qa_out = dup_string(qa);
+  *ta_out = dup_string(ta);
+  *qa_len = qa.size();
+  if (!*qa_out || !*ta_out) {
+    free(*qa_out);
+    free(*ta_out);
+    return false;
+  }
+  return true;
 }
 
-Result* box_result(const std::string& qa, const std::string& ta, int path, const PairOut& o) {
+// takes ownership of qa / ta; the caller registers the strings (register_results)
+ResultBox* box_result(char* qa, char* ta, int path, const PairOut& o) {
   ResultBox* b = (ResultBox*)calloc(1, sizeof(ResultBox));
-  if (!b) return nullptr;
-  b->r.query_ptr = dup_string(qa);
-  b->r.target_ptr = dup_string(ta);
-  if (!b->r.query_ptr || !b->r.target_ptr) {
-    free(b->r.query_ptr);
-    free(b->r.target_ptr);
-    free(b);
+  if (!b) {
+    free(qa);
+    free(ta);
     return nullptr;
   }
+  b->r.query_ptr = qa;
+  b->r.target_ptr = ta;
   b->magic = kMagic;
   if (path == SW_PATH_STRAIGHT) {  // rust/src/lib.rs:70: (.., 0, x, y)
     b->score32 = 0;
@@ -414,30 +472,39 @@ Result* box_result(const std::string& qa, const std::string& ta, int path, const
     b->r.max_x = (uint64_t)o.bx - 1;
     b->r.max_y = (uint64_t)o.bj - 1;
   }
+  return b;
+}
+void register_results(Result* const* res, size_t n) {
   std::lock_guard<std::mutex> lk(g_str_mu);
-  g_live_strings[b->r.query_ptr] = b;
-  g_live_strings[b->r.target_ptr] = b;
-  return &b->r;
+  for (size_t i = 0; i < n; i++) {
+    if (!res[i]) continue;
+    ResultBox* b = (ResultBox*)res[i];
+    g_live_strings[b->r.query_ptr] = b;
+    g_live_strings[b->r.target_ptr] = b;
+  }
 }
 
 Scoring to_scoring(AlignmentScores s) {
   return Scoring{(int)(int16_t)s.match, (int)(int16_t)s.miss, (int)(int16_t)s.gap};
 }
 
-struct Decoded {
-  std::vector<uint32_t> cps;
-  std::vector<uint16_t> sym;
-};
-bool decode(const char* s, Decoded& d) {
-  if (!s || !decode_utf8(s, d.cps)) return false;
-  d.sym.resize(d.cps.size());
-  for (size_t i = 0; i < d.cps.size(); i++) d.sym[i] = (uint16_t)d.cps[i];
-  return true;
-}
-
 // The reference panics (-> NULL) on the ring path when gap == 0 (rust/src/algorithm/mod.rs:236-238).
 bool ring_div_by_zero(int path, uint32_t Q, uint32_t T, Scoring sc) {
   return path == SW_PATH_LOW_MEMORY && !((uint64_t)T < 2ull * Q) && sc.gap == 0;
+}
+
+// host threads for the byte loops around a big submission (decoding, string assembly)
+template <class F>
+void parallel_ranges(size_t n, size_t work, F&& f) {
+  unsigned nt = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+  if (work < (1u << 20) || n < 2 * nt) nt = 1;
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; t++) {
+    const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+    if (t + 1 == nt) f(lo, hi);
+    else th.emplace_back([=, &f] { f(lo, hi); });
+  }
+  for (auto& x : th) x.join();
 }
 
 int align_many(const char* const* queries, const char* const* targets, size_t n, AlignmentScores as, int path,
@@ -446,32 +513,65 @@ int align_many(const char* const* queries, const char* const* targets, size_t n,
   if (!queries || !targets || !out) return fail(SW_E_ARG, "null argument");
   if (path < 0 || path > 2) return fail(SW_E_ARG, "bad path");
   const Scoring sc = to_scoring(as);
-  std::vector<Decoded> dq(n), dt(n);
+  // A work package names the same sequences over and over (worker_impl.go:115-117): decode each distinct input
+  // pointer once.
+  std::unordered_map<const char*, uint32_t> seen;
+  std::vector<const char*> distinct;
+  std::vector<uint32_t> qi(n), ti(n);
+  auto intern = [&](const char* s) -> uint32_t {
+    if (!s) return UINT32_MAX;
+    auto it = seen.find(s);
+    if (it != seen.end()) return it->second;
+    const uint32_t id = (uint32_t)distinct.size();
+    distinct.push_back(s);
+    seen.emplace(s, id);
+    return id;
+  };
+  for (size_t i = 0; i < n; i++) {
+    out[i] = nullptr;
+    qi[i] = intern(queries[i]);
+    ti[i] = intern(targets[i]);
+  }
+  std::vector<Decoded> dec(distinct.size());
+  std::vector<uint8_t> ok(distinct.size(), 0);
+  std::vector<size_t> lens(distinct.size());
+  size_t total_bytes = 0;
+  for (size_t d = 0; d < distinct.size(); d++) total_bytes += (lens[d] = strlen(distinct[d]));
+  parallel_ranges(distinct.size(), total_bytes, [&](size_t lo, size_t hi) {
+    for (size_t d = lo; d < hi; d++)  // bindings.rs:125 unwrap: invalid UTF-8 -> NULL
+      ok[d] = decode(distinct[d], lens[d], dec[d]) && dec[d].sym.size() < 0x7fffff00u;
+  });
   std::vector<PairSpec> specs;
   std::vector<size_t> idx;
   specs.reserve(n);
+  idx.reserve(n);
   for (size_t i = 0; i < n; i++) {
-    out[i] = nullptr;
-    if (!decode(queries[i], dq[i]) || !decode(targets[i], dt[i])) continue;  // bindings.rs:125 unwrap -> NULL
-    if (dq[i].sym.size() >= 0x7fffff00u || dt[i].sym.size() >= 0x7fffff00u) continue;
-    if (ring_div_by_zero(path, (uint32_t)dq[i].sym.size(), (uint32_t)dt[i].sym.size(), sc)) continue;
-    specs.push_back(PairSpec{dq[i].sym.data(), (uint32_t)dq[i].sym.size(), dt[i].sym.data(), (uint32_t)dt[i].sym.size(), path});
+    if (qi[i] == UINT32_MAX || ti[i] == UINT32_MAX || !ok[qi[i]] || !ok[ti[i]]) continue;
+    const Decoded &q = dec[qi[i]], &t = dec[ti[i]];
+    if (ring_div_by_zero(path, (uint32_t)q.sym.size(), (uint32_t)t.sym.size(), sc)) continue;
+    specs.push_back(PairSpec{q.sym.data(), (uint32_t)q.sym.size(), t.sym.data(), (uint32_t)t.sym.size(), path});
     idx.push_back(i);
   }
   std::vector<PairOut> po(specs.size());
+  std::vector<uint8_t> arena;
   {
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     int rc = ctx_init_locked(-1);
     if (rc) return rc;
-    rc = run_exact(specs.data(), specs.size(), sc, true, po.data());
+    rc = run_exact(specs.data(), specs.size(), sc, true, po.data(), &arena);
     if (rc) return rc;
   }
-  std::string qa, ta;
-  for (size_t k = 0; k < specs.size(); k++) {
-    size_t i = idx[k];
-    build_alignment(dq[i].cps, dt[i].cps, po[k], qa, ta);
-    out[i] = box_result(qa, ta, path, po[k]);
-  }
+  parallel_ranges(specs.size(), arena.size() * 4, [&](size_t lo, size_t hi) {
+    for (size_t k = lo; k < hi; k++) {
+      const size_t i = idx[k];
+      char *qa = nullptr, *ta = nullptr;
+      size_t qlen = 0;
+      if (!build_alignment(dec[qi[i]], dec[ti[i]], po[k], arena.data() + po[k].ops_off, &qa, &ta, &qlen)) continue;
+      ResultBox* b = box_result(qa, ta, path, po[k]);
+      out[i] = b ? &b->r : nullptr;
+    }
+  });
+  register_results(out, n);
   return SW_OK;
 }
 
@@ -683,6 +783,16 @@ sw_db* db_build(std::string&& flat, std::vector<uint64_t>&& off) {
     db_release(db);
     fail(SW_E_ARG, "NUL byte inside a sequence");
     return nullptr;
+  }
+  // sequences are text like the per-pair inputs (bindings.rs:125-129): anything non-ASCII must be valid UTF-8
+  for (uint64_t i = 0; i < db->n; i++) {
+    if (db->packed_ok[i]) continue;
+    Decoded d;
+    if (!decode(db->flat.data() + db->off[i], (size_t)(db->off[i + 1] - db->off[i]), d)) {
+      db_release(db);
+      fail(SW_E_ARG, "sequence " + std::to_string(i) + " is not valid UTF-8");
+      return nullptr;
+    }
   }
   std::vector<uint32_t> packable;
   for (uint64_t i = 0; i < db->n; i++) {
@@ -930,13 +1040,12 @@ int rescore_locked(sw_db* db, const QueryPrep& qp, Scoring sc, const std::vector
   if (rerun.empty()) return SW_OK;
   const uint32_t Q = (uint32_t)qp.d.sym.size();
   std::vector<PairSpec> specs(rerun.size());
-  std::vector<std::vector<uint16_t>> tsym(rerun.size());
+  std::vector<Decoded> tdec(rerun.size());
   for (size_t k = 0; k < rerun.size(); k++) {
     uint32_t ti = rerun[k];
-    const unsigned char* s = (const unsigned char*)db->flat.data() + db->off[ti];
-    uint32_t T = (uint32_t)(db->off[ti + 1] - db->off[ti]);
-    tsym[k].assign(s, s + T);
-    specs[k] = PairSpec{qp.d.sym.data(), Q, tsym[k].data(), T, SW_PATH_LOW_MEMORY};
+    // (valid UTF-8: checked when the database was built)
+    decode(db->flat.data() + db->off[ti], (size_t)(db->off[ti + 1] - db->off[ti]), tdec[k]);
+    specs[k] = PairSpec{qp.d.sym.data(), Q, tdec[k].sym.data(), (uint32_t)tdec[k].sym.size(), SW_PATH_LOW_MEMORY};
   }
   std::vector<PairOut> po(rerun.size());
   int rc = run_exact(specs.data(), specs.size(), sc, false, po.data());
@@ -1083,7 +1192,7 @@ bool prep_query(const char* query, QueryPrep& qp) {
   const size_t Q = qp.d.sym.size();
   qp.qwords.assign((Q + 15) / 16 + 1, 0);
   for (size_t i = 0; i < Q; i++) {
-    int code = qp.d.cps[i] < 128 ? nt_code((unsigned char)qp.d.cps[i]) : -1;
+    int code = qp.d.cp(i) < 128 ? nt_code((unsigned char)qp.d.cp(i)) : -1;
     if (code < 0) {
       qp.acgt = false;
       code = 0;
@@ -1164,8 +1273,9 @@ int sw_db_search_topk_batch(sw_db* db, const char* const* queries, size_t n_quer
   const Scoring sc = to_scoring(as);
   std::vector<std::vector<TopEntry>> tops(n_queries);
   std::vector<PairSpec> specs;
-  std::vector<std::vector<uint16_t>> tsym;
+  std::vector<Decoded> tdec;
   std::vector<PairOut> po;
+  std::vector<uint8_t> arena;
   {
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     int rc = ctx_init_locked(-1);
@@ -1179,44 +1289,45 @@ int sw_db_search_topk_batch(sw_db* db, const char* const* queries, size_t n_quer
       total += tops[q].size();
     }
     specs.reserve(total);
-    tsym.resize(total);
+    tdec.resize(total);
     size_t at = 0;
     for (size_t q = 0; q < n_queries; q++)
       for (const TopEntry& e : tops[q]) {
-        const unsigned char* s = (const unsigned char*)db->flat.data() + db->off[e.target];
-        const uint32_t T = (uint32_t)(db->off[e.target + 1] - db->off[e.target]);
-        tsym[at].assign(s, s + T);
-        specs.push_back(PairSpec{qps[q].d.sym.data(), (uint32_t)qps[q].d.sym.size(), tsym[at].data(), T, SW_PATH_LOW_MEMORY});
+        decode(db->flat.data() + db->off[e.target], (size_t)(db->off[e.target + 1] - db->off[e.target]), tdec[at]);
+        specs.push_back(PairSpec{qps[q].d.sym.data(), (uint32_t)qps[q].d.sym.size(), tdec[at].sym.data(),
+                                 (uint32_t)tdec[at].sym.size(), SW_PATH_LOW_MEMORY});
         at++;
       }
     po.resize(total);
-    rc = run_exact(specs.data(), total, sc, true, po.data());
+    rc = run_exact(specs.data(), total, sc, true, po.data(), &arena);
     if (rc) return rc;
   }
-  std::string qa, ta;
-  std::vector<uint32_t> tcps;
   size_t at = 0;
   for (size_t q = 0; q < n_queries; q++) {
     for (size_t i = 0; i < tops[q].size(); i++, at++) {
       const TopEntry& e = tops[q][i];
-      tcps.assign(tsym[at].begin(), tsym[at].end());
-      build_alignment(qps[q].d.cps, tcps, po[at], qa, ta);
-      if (po[at].score != e.score) {
+      char *qa = nullptr, *ta = nullptr;
+      size_t qlen = 0;
+      const bool built = build_alignment(qps[q].d, tdec[at], po[at], arena.data() + po[at].ops_off, &qa, &ta, &qlen);
+      if (!built || po[at].score != e.score) {
+        free(qa);
+        free(ta);
         for (size_t r = 0; r < n_queries; r++) {
           sw_hits_free(hits + r * (size_t)k, n_hits[r]);
           n_hits[r] = 0;
         }
+        if (!built) return fail(SW_E_NOMEM, "out of memory");
         return fail(SW_E_HIP, "internal: score kernel and exact kernel disagree on target " + std::to_string(e.target) +
                                   " (" + std::to_string(e.score) + " vs " + std::to_string(po[at].score) + ")");
       }
       sw_hit& h = hits[q * (size_t)k + i];
       h.target_index = e.target;
       h.score = po[at].score;
-      h.length = (uint32_t)qa.size();
+      h.length = (uint32_t)qlen;
       h.max_x = (uint64_t)po[at].bx - 1;
       h.max_y = (uint64_t)po[at].bj - 1;
-      h.query_aln = dup_string(qa);
-      h.target_aln = dup_string(ta);
+      h.query_aln = qa;
+      h.target_aln = ta;
       n_hits[q] = (int)i + 1;
     }
   }

@@ -54,39 +54,40 @@ __global__ void __launch_bounds__(1024) sw_hist_kernel(SelectParams p) {
     if (h[i]) atomicAdd(p.hist + i, h[i]);
 }
 
-// one workgroup of 1024 threads; thread t owns bins [32 t, 32 t + 32)
+// one workgroup of 1024 threads; thread t owns bins [32 t, 32 t + 32).  Suffix sums over the 1024 partial counts
+// (log-step scan in LDS) locate the one thread whose bins contain the k-th best score.
 __global__ void __launch_bounds__(1024) sw_thresh_kernel(SelectParams p) {
-  __shared__ uint32_t part[1024];
+  __shared__ uint32_t part[2][1024];
   const uint32_t t = threadIdx.x;
+  uint32_t bins[32];
   uint32_t mine = 0;
-  for (uint32_t i = 0; i < 32; i++) mine += p.hist[t * 32 + i];
-  part[t] = mine;
+  for (uint32_t i = 0; i < 32; i++) {
+    bins[i] = p.hist[t * 32 + i];
+    mine += bins[i];
+  }
+  part[0][t] = mine;
   __syncthreads();
-  if (t == 0) {
-    // walk down from the top bin; serial over 1024 partial sums + at most 32 bins
-    uint32_t above = 0, thr = 0;
-    bool found = false;
-    for (int b = 1023; b >= 0 && !found; b--) {
-      if (above + part[b] >= p.k) {
-        for (int i = 31; i >= 0; i--) {
-          const uint32_t c = p.hist[b * 32 + i];
-          if (above + c >= p.k) {
-            thr = (uint32_t)(b * 32 + i);
-            found = true;
-            break;
-          }
-          above += c;
-        }
-      } else {
-        above += part[b];
+  int cur = 0;
+  for (uint32_t d = 1; d < 1024; d <<= 1) {  // part[cur][t] = sum of mine over threads t .. min(t + 2d - 1, 1023)
+    part[cur ^ 1][t] = part[cur][t] + (t + d < 1024 ? part[cur][t + d] : 0u);
+    cur ^= 1;
+    __syncthreads();
+  }
+  const uint32_t incl = part[cur][t];  // slots with a score in my bins or above
+  uint32_t above = incl - mine;        // ... strictly above my bins
+  if (above < p.k && p.k <= incl) {
+    for (int i = 31; i >= 0; i--) {
+      if (above + bins[i] >= p.k) {
+        p.counters[kSelThresh] = t * 32 + (uint32_t)i;
+        p.counters[kSelAbove] = above;
+        break;
       }
+      above += bins[i];
     }
-    if (!found) {  // fewer than k plain slots: everything is a candidate
-      thr = 0;
-      above -= p.hist[0];
-    }
-    p.counters[kSelThresh] = thr;
-    p.counters[kSelAbove] = above;
+  }
+  if (t == 0 && incl < p.k) {  // fewer than k plain slots: everything is a candidate
+    p.counters[kSelThresh] = 0;
+    p.counters[kSelAbove] = incl - bins[0];
   }
 }
 

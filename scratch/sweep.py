@@ -48,6 +48,30 @@ def pair_case(name, Q, T, mutate=None):
     print(json.dumps({"case": name, "Q": Q, "T": T, "s": round(dt, 4), "gcups": round(Q * T / dt / 1e9, 2), "kernels_ms": round(kms, 3),
                       "score": None if r0 is None else r0.score, "alen": None if r0 is None else len(r0.query)}), flush=True)
 
+def batch_case(name, qlen, lens, nq=1):
+    """ExecuteWork's shape: every pair of the package through sw_align_batch (exact kernel + traceback for all)."""
+    rng = np.random.default_rng(5)
+    qs = [synth(rng, np.array([qlen]))[0].tobytes() for _ in range(nq)]
+    flat, offs = synth(rng, lens)
+    ts = [flat[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(len(lens))]
+    Qs = [q for q in qs for _ in ts]; Ts = ts * nq
+    sc = dlsa_amd.AlignmentScore(2, -1, -1)
+    best = 1e9
+    for _ in range(3):
+        k0 = bridge.last_stats()["exact_kernel_ms"]
+        import ctypes as C
+        L = bridge.lib(); n = len(Qs)
+        qa = (C.c_char_p * n)(*Qs); ta = (C.c_char_p * n)(*Ts); out = (C.POINTER(bridge.CResult) * n)()
+        t0 = time.perf_counter(); rc = L.sw_align_batch(qa, ta, n, sc.c(), 0, out); dt = time.perf_counter() - t0
+        assert rc == 0
+        t1 = time.perf_counter()
+        for i in range(n): L.free_alignment_result(out[i])
+        tfree = time.perf_counter() - t1
+        best = min(best, dt); kms = bridge.last_stats()["exact_kernel_ms"] - k0
+    cells = float(qlen) * float(lens.sum()) * nq
+    print(json.dumps({"case": name, "pairs": len(Qs), "cells": cells, "ms": round(best * 1e3, 2), "gcups": round(cells / best / 1e9, 1),
+                      "free_ms": round(tfree * 1e3, 2), "kernels_ms": round(kms, 3), "kernel_gcups": round(cells / kms / 1e6, 1)}), flush=True)
+
 which = sys.argv[1:]
 rng = np.random.default_rng(3)
 if "c1" in which: db_case("C1 1kb x 1000x[900,1100]", 1000, rng.integers(900, 1101, size=1000))
@@ -59,3 +83,6 @@ if "p20k" in which: pair_case("pair 20k", 20000, 20000)
 if "p50k" in which: pair_case("pair 50k", 50000, 50000)
 if "c4" in which: pair_case("C4 100k", 100000, 100000)
 if "c4m" in which: pair_case("C4 100k 5% mutated", 100000, 100000, 0.05)
+if "b1" in which: batch_case("ExecuteWork C1: 1kb x 1000x[900,1100] all pairs", 1000, rng.integers(900, 1101, size=1000))
+if "b2" in which: batch_case("ExecuteWork 32 x 1000 pairs of ~1kb", 1000, rng.integers(900, 1101, size=1000), nq=8)
+if "b5" in which: batch_case("ExecuteWork 150 x 100000x150", 150, np.full(100000, 150))
