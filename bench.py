@@ -82,10 +82,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    # Rehearsal of the N > 1 path on a ONE-GPU box (SW_BENCH_REHEARSAL=1): every rank uses device 0 and the
+    # hit records travel over gloo, because RCCL refuses two ranks on one device.  Never used by the driver.
+    rehearsal = os.environ.get("SW_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
@@ -103,7 +111,7 @@ def main():
     flat, offsets = synth(np.random.default_rng(SEED + 1 + rank), n_targets, T_LEN)
     db = bridge.Database(flat=flat, offsets=offsets)
     score = dlsa_amd.AlignmentScore(MATCH, MISMATCH, GAP)
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
 
     def barrier():
         torch.cuda.synchronize()

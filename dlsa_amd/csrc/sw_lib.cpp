@@ -85,6 +85,7 @@ int ctx_init_locked(int device) {
   Context& c = g_ctx;
   if (c.ready) {
     if (device >= 0 && device != c.device) return fail(SW_E_ARG, "sw_hip_init: already initialised on another device");
+    HIPCK(hipSetDevice(c.device));  // HIP's current device is per thread; the ABI is entered from many threads
     return SW_OK;
   }
   int n = 0;
