@@ -204,12 +204,17 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
       for (int r = 0; r < RPL; r++) w[r * 64] = acc[r];
     }
     if (feeds && lane == 63) {
-      // lane 63 finished columns 16 g - 62 .. 16 g - 47 of the strip's bottom row during this block
+      // lane 63 finished columns 16 g - 62 .. 16 g - 47 of the strip's bottom row during this block: four 16-byte
+      // device-scope stores (a wave may only have 63 memory operations in flight; sixteen dword stores per block
+      // on top of the direction words made the producer wait for its own stores)
       const int col0 = (int)(g * 16) - 62;
       if (col0 >= 1 && (uint32_t)(col0 + 15) <= maxcol) {
+        typedef int i4v __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-          __hip_atomic_store(bout + col0 + i, hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 0; i < 16; i += 4) {
+          const i4v v = {hist[i], hist[i + 1], hist[i + 2], hist[i + 3]};
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(bout + col0 + i), "v"(v) : "memory");
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < 16; i++)

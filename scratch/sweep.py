@@ -86,3 +86,6 @@ if "c4m" in which: pair_case("C4 100k 5% mutated", 100000, 100000, 0.05)
 if "b1" in which: batch_case("ExecuteWork C1: 1kb x 1000x[900,1100] all pairs", 1000, rng.integers(900, 1101, size=1000))
 if "b2" in which: batch_case("ExecuteWork 32 x 1000 pairs of ~1kb", 1000, rng.integers(900, 1101, size=1000), nq=8)
 if "b5" in which: batch_case("ExecuteWork 150 x 100000x150", 150, np.full(100000, 150))
+if "strips" in which:
+    for Q in (256, 1024, 2560, 25600):
+        pair_case(f"strip timing Q={Q}", Q, 100000)
