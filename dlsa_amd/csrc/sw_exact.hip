@@ -312,7 +312,7 @@ __global__ void __launch_bounds__(64) sw_exact_kernel(ExactWork W, int match, in
 // direction words (8 blocks of 16 steps x 256 rows of the current strip = 8 KB, coalesced), the strip's query
 // symbols and the matching target range in LDS and walks inside it with wave-uniform (scalar) state; within a
 // strip the step index k = j - 1 + lane(row) never increases along the walk, so a window is left only downwards
-// or when the path crosses into the strip above.  Ops are collected one per lane and flushed 64 at a time.
+// or when the path crosses into the strip above.
 constexpr uint32_t WKB = 8;  // 16-step blocks per window
 __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, ExactOut* outs, uint32_t n,
                                                      int match, int miss, int gap) {
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
   const uint32_t bx = (uint32_t)__builtin_amdgcn_readfirstlane((int)outs[p].bx);
   const uint32_t bj = (uint32_t)__builtin_amdgcn_readfirstlane((int)outs[p].bj);
   const uint32_t cap = P.Q + P.T;
-  uint32_t nops = 0, myop = 0;
+  uint32_t nops = 0;
   if (H > 0 && bx > 0 && bj > 0) {
     // wave-uniform walk state: strip, row inside the strip, target index j - 1
     uint32_t strip = (bx - 1) / SH;
@@ -348,7 +348,10 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
         const uint32_t* src = P.dirs + ((size_t)(strip * P.nkb + wbase) * RPL) * 64 + lane;
         uint32_t v[WKB * RPL];
 #pragma unroll
-        for (uint32_t u = 0; u < WKB * RPL; u++) v[u] = (u < nb * RPL) ? src[(size_t)u * 64] : 0u;
+        for (uint32_t u = 0; u < WKB * RPL; u++) {  // blocks past the window top are clamped (never read back)
+          const uint32_t blk = u / RPL < nb ? u / RPL : nb - 1;
+          v[u] = src[((size_t)blk * RPL + u % RPL) * 64];
+        }
         uint32_t qv[SH / 64], tv[(WKB * 16 + 64) / 64];
 #pragma unroll
         for (uint32_t u = 0; u < SH / 64; u++) {
@@ -369,45 +372,61 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
         for (uint32_t u = 0; u < (WKB * 16 + 64) / 64; u++) wt[u * 64 + lane] = tv[u];
       }
       __syncthreads();
-      // ---- walk inside the window.  Every lane carries the same state in VECTOR registers and the step is
-      // branch-free (a lone wave issues one instruction per 4 cycles whatever its type, and a taken branch
-      // costs several): three LDS reads, a dozen VALU operations and one loop branch per step.
+      // ---- walk inside the window: one diagonal RUN plus the gap move that ends it per iteration.  Lane t
+      // looks at the cell t diagonal moves further on; a ballot gives the length of the run, its H bookkeeping
+      // is two popcounts (v_mbcnt) because a diagonal step subtracts either match or miss, and the first
+      // non-diagonal cell's code is already in its lane.  Alignments of related sequences are long diagonal
+      // runs: tens of steps per LDS round trip instead of one.
       const int wlo = (int)(wbase * 16);  // smallest step index covered
-      int vH = H, vwithin = within, vjm1 = jm1;
-      // keep the compiler from proving the state wave-uniform and turning the step into scalar code + branches
-      asm volatile("" : "+v"(vH), "+v"(vwithin), "+v"(vjm1));
       for (;;) {
-        const int k = vjm1 + (vwithin >> 2);
-        if (k < wlo) break;  // window exhausted (same strip)
-        const uint32_t w = wdir[(((uint32_t)k >> 4) - wbase) * SH + (uint32_t)vwithin];
-        const uint32_t qsym = wq[vwithin];
-        const uint32_t tsym = wt[vjm1 - tbase];
-        const uint32_t code = w >> ((~(uint32_t)k & 15u) * 2);
-        const bool diag = code & 1u;
-        const bool up = !diag && (code & 2u);
-        const int sub = (qsym == tsym) ? match : miss;
-        vH -= diag ? sub : gap;
-        vwithin -= (diag || up) ? 1 : 0;
-        vjm1 -= up ? 0 : 1;
-        const uint32_t op = diag ? 0u : (up ? 1u : 2u);
-        if (lane == (nops & 63u)) myop = op;
-        nops++;
-        if ((nops & 63u) == 0) P.ops[nops - 64 + lane] = (uint8_t)myop;
-        if (vH <= 0 || vjm1 < 0 || vwithin < 0 || nops >= cap) break;
-      }
-      H = __builtin_amdgcn_readfirstlane(vH);
-      within = __builtin_amdgcn_readfirstlane(vwithin);
-      jm1 = __builtin_amdgcn_readfirstlane(vjm1);
-      if (H <= 0 || jm1 < 0 || nops >= cap) {
-        go = false;
-      } else if (within < 0) {  // into the strip above (or off the top edge)
-        if (strip == 0) go = false;
-        strip--;
-        within = SH - 1;
+        const int k0 = jm1 + (within >> 2);
+        if (k0 < wlo) break;  // window exhausted (same strip)
+        const int wr = within - (int)lane, jt = jm1 - (int)lane;
+        const int kt = jt + (wr >> 2);
+        const bool valid = wr >= 0 && jt >= 0 && kt >= wlo;
+        uint32_t code = 0;
+        bool eq = false;
+        if (valid) {
+          const uint32_t w = wdir[(((uint32_t)kt >> 4) - wbase) * SH + (uint32_t)wr];
+          code = (w >> ((~(uint32_t)kt & 15u) * 2)) & 3u;
+          eq = wq[wr] == wt[jt - tbase];
+        }
+        const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
+        const uint64_t run = __builtin_amdgcn_ballot_w64(valid && (code & 1u));
+        const uint32_t L = ~run ? (uint32_t)__builtin_ctzll(~run) : 64u;  // diagonal moves from here
+        const uint64_t eqm = __builtin_amdgcn_ballot_w64(eq);
+        const int neq = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(eqm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)eqm, 0u));
+        const int h_before = H - match * neq - miss * ((int)lane - neq);  // H at lane t's cell if all before were diagonal
+        const int h_after = h_before - (eq ? match : miss);
+        const uint64_t stop = __builtin_amdgcn_ballot_w64(lane < L && h_after <= 0);  // the walk ends where H reaches 0
+        // branch-free bookkeeping (every taken branch costs a lone wave several issue slots)
+        const uint32_t nd = stop ? min(L, (uint32_t)__builtin_ctzll(stop) + 1u) : L;  // diagonal moves taken
+        const bool take_gap = !stop && L < 64 && ((vmask >> (L & 63u)) & 1ull);  // the cell that ended the run is in reach
+        const int h_run = __builtin_amdgcn_readlane(h_after, (int)(nd ? nd - 1 : 0));
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)code, (int)(L & 63u));
+        const bool up = take_gap && (c & 2u);
+        const bool left = take_gap && !(c & 2u);
+        H = (nd ? h_run : H) - (take_gap ? gap : 0);
+        within -= (int)nd + (up ? 1 : 0);
+        jm1 -= (int)nd + (left ? 1 : 0);
+        uint32_t n = nd + (take_gap ? 1u : 0u);
+        const uint32_t op = (take_gap && lane == n - 1) ? (up ? 1u : 2u) : 0u;
+        if (nops + n > cap) n = cap - nops;
+        if (lane < n) P.ops[nops + lane] = (uint8_t)op;
+        nops += n;
+        if (H <= 0 || jm1 < 0 || nops >= cap) {
+          go = false;
+          break;
+        }
+        if (within < 0) {  // into the strip above (or off the top edge)
+          if (strip == 0) go = false;
+          strip--;
+          within = SH - 1;
+          break;
+        }
       }
     }
   }
-  if (lane < (nops & 63u)) P.ops[(nops & ~63u) + lane] = (uint8_t)myop;
   if (lane == 0) outs[p].nops = nops;
 }
 

@@ -49,8 +49,9 @@ struct ExactOut {
 constexpr int kExactRPL = 4;             // rows per lane
 constexpr int kExactSH = 64 * kExactRPL; // rows per strip
 
-// steps per strip (multiple of 64) for a pair whose widest row has `maxcol` columns
-__host__ __device__ inline uint32_t exact_nsteps(uint32_t maxcol) { return maxcol == 0 ? 0 : ((maxcol + 63 + 63) / 64) * 64; }
+// steps per strip (multiple of 16: lane 63 reaches column maxcol at step maxcol + 62) for a pair whose widest
+// row has `maxcol` columns
+__host__ __device__ inline uint32_t exact_nsteps(uint32_t maxcol) { return maxcol == 0 ? 0 : ((maxcol + 63 + 15) / 16) * 16; }
 __host__ __device__ inline uint32_t exact_nstrips(uint32_t Q) { return (Q + kExactSH - 1) / kExactSH; }
 inline size_t exact_dir_words(uint32_t Q, uint32_t maxcol) {
   return (size_t)exact_nstrips(Q) * (exact_nsteps(maxcol) / 16) * kExactRPL * 64;
