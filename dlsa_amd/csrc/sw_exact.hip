@@ -24,8 +24,7 @@ namespace swhip {
 
 namespace {
 
-constexpr int RPL = kExactRPL;
-constexpr int SH = kExactSH;
+constexpr int kMaxRPL = 4;  // rows per lane: 4, 2 or 1, chosen per launch (ExactWork::rpl)
 
 __device__ __forceinline__ int dpp_wave_shr1(int fill_lane0, int v) {
   // lane i <- lane i-1; lane 0 keeps `fill_lane0` (bound_ctrl = 0)
@@ -81,7 +80,7 @@ __device__ __forceinline__ uint32_t push_dir_bits(uint32_t acc, int a1, int b1, 
 // started, rows >= Q of the last strip) need no masking there, because with sentinel symbols that never match
 // they evaluate to 0 from zero inputs, and phantom rows below the matrix only see values strictly smaller than
 // a real cell's, so they never win the maximum.  MASK = true handles the right edge and odd scorings.
-template <bool DIRS, bool MASK>
+template <int RPL, bool DIRS, bool MASK>
 __device__ __forceinline__ void exact_steps16(const uint32_t (&qs)[RPL], const bool (&valid)[RPL], int (&h)[RPL],
                                               int (&bestv)[RPL], uint32_t (&bestj)[RPL], uint32_t (&acc)[RPL],
                                               int& top_prev, int& last_out, int& tcur, int (&hist)[16], int& jv,
@@ -129,7 +128,7 @@ __device__ __forceinline__ void exact_steps16(const uint32_t (&qs)[RPL], const b
   }
 }
 
-template <bool DIRS>
+template <int RPL, bool DIRS>
 __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork& W, uint32_t strip, int match,
                                             int miss, int gap, int& gbv, uint64_t& gkey) {
   const int lane = threadIdx.x & 63;
@@ -137,7 +136,8 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
   const uint32_t maxcol = P.Tlim > P.T0 ? P.Tlim : P.T0;
   const uint32_t mincol = P.Tlim < P.T0 ? P.Tlim : P.T0;
   const uint32_t NG = exact_nsteps(maxcol) / 16;  // 16-step blocks
-  const uint32_t nstrips = exact_nstrips(Q);
+  constexpr uint32_t SH = 64 * RPL;
+  const uint32_t nstrips = exact_nstrips(Q, RPL);
 
   const int32_t* bin = P.bnd + (size_t)(strip > 0 ? strip - 1 : 0) * P.bnd_pitch;  // bottom row of strip-1
   int32_t* bout = P.bnd + (size_t)strip * P.bnd_pitch;
@@ -193,10 +193,10 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
       tnext = fetch_t(g + 1);
     }
     if (plain && g * 16 + 16 <= mincol)
-      exact_steps16<DIRS, false>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
+      exact_steps16<RPL, DIRS, false>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
                                  match, miss, gap, lim0, P.Tlim);
     else
-      exact_steps16<DIRS, true>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
+      exact_steps16<RPL, DIRS, true>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
                                 match, miss, gap, lim0, P.Tlim);
     if (DIRS) {
       uint32_t* w = P.dirs + ((size_t)(strip * P.nkb + g) * RPL) * 64 + lane;
@@ -247,6 +247,7 @@ __device__ __forceinline__ void wave_best(int& gbv, uint64_t& gkey) {
   }
 }
 
+template <int RPL>
 __global__ void __launch_bounds__(64) sw_exact_kernel(ExactWork W, int match, int miss, int gap) {
   const int lane = threadIdx.x;
   uint32_t t = 0;
@@ -259,11 +260,11 @@ __global__ void __launch_bounds__(64) sw_exact_kernel(ExactWork W, int match, in
   const uint32_t maxcol = P.Tlim > P.T0 ? P.Tlim : P.T0;
   int gbv = 0;
   uint64_t gkey = ~0ull;
-  if (strip < exact_nstrips(P.Q) && maxcol > 0) {
+  if (strip < exact_nstrips(P.Q, RPL) && maxcol > 0) {
     if (P.dirs)
-      exact_strip<true>(P, W, strip, match, miss, gap, gbv, gkey);
+      exact_strip<RPL, true>(P, W, strip, match, miss, gap, gbv, gkey);
     else
-      exact_strip<false>(P, W, strip, match, miss, gap, gbv, gkey);
+      exact_strip<RPL, false>(P, W, strip, match, miss, gap, gbv, gkey);
   }
   wave_best(gbv, gkey);
   // The last strip of a pair to finish combines the per-strip records (threadfence reduction).
@@ -314,8 +315,11 @@ __global__ void __launch_bounds__(64) sw_exact_kernel(ExactWork W, int match, in
 // strip the step index k = j - 1 + lane(row) never increases along the walk, so a window is left only downwards
 // or when the path crosses into the strip above.
 constexpr uint32_t WKB = 8;  // 16-step blocks per window
+template <int RPL>
 __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, ExactOut* outs, uint32_t n,
                                                      int match, int miss, int gap) {
+  constexpr int SH = 64 * RPL;
+  constexpr int LOG_RPL = RPL == 4 ? 2 : (RPL == 2 ? 1 : 0);
   __shared__ uint32_t wdir[WKB * SH];  // [block][row of the strip]
   __shared__ uint32_t wq[SH];
   __shared__ uint32_t wt[WKB * 16 + 64];
@@ -338,7 +342,7 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
     bool go = true;
     while (go) {
       // ---- stage a window: blocks [wbase, wtop] of this strip; all loads in flight before the first LDS write
-      const uint32_t ktop = (uint32_t)jm1 + ((uint32_t)within >> 2);
+      const uint32_t ktop = (uint32_t)jm1 + ((uint32_t)within >> LOG_RPL);
       const uint32_t wtop = ktop >> 4;
       const uint32_t wbase = wtop >= WKB - 1 ? wtop - (WKB - 1) : 0;
       const uint32_t nb = wtop - wbase + 1;
@@ -379,10 +383,10 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
       // runs: tens of steps per LDS round trip instead of one.
       const int wlo = (int)(wbase * 16);  // smallest step index covered
       for (;;) {
-        const int k0 = jm1 + (within >> 2);
+        const int k0 = jm1 + (within >> LOG_RPL);
         if (k0 < wlo) break;  // window exhausted (same strip)
         const int wr = within - (int)lane, jt = jm1 - (int)lane;
-        const int kt = jt + (wr >> 2);
+        const int kt = jt + (wr >> LOG_RPL);
         const bool valid = wr >= 0 && jt >= 0 && kt >= wlo;
         uint32_t code = 0;
         bool eq = false;
@@ -434,15 +438,31 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
 
 hipError_t launch_exact(const ExactWork& w, Scoring sc, hipStream_t stream) {
   if (w.n_units == 0) return hipSuccess;
-  hipLaunchKernelGGL(sw_exact_kernel, dim3(w.n_units), dim3(64), 0, stream, w, sc.match, sc.miss, sc.gap);
+  if (w.rpl == 4)
+    hipLaunchKernelGGL(sw_exact_kernel<4>, dim3(w.n_units), dim3(64), 0, stream, w, sc.match, sc.miss, sc.gap);
+  else if (w.rpl == 2)
+    hipLaunchKernelGGL(sw_exact_kernel<2>, dim3(w.n_units), dim3(64), 0, stream, w, sc.match, sc.miss, sc.gap);
+  else if (w.rpl == 1)
+    hipLaunchKernelGGL(sw_exact_kernel<1>, dim3(w.n_units), dim3(64), 0, stream, w, sc.match, sc.miss, sc.gap);
+  else
+    return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
-hipError_t launch_walk(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, Scoring sc,
+hipError_t launch_walk(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, int rpl, Scoring sc,
                        hipStream_t stream) {
   if (n_pairs == 0) return hipSuccess;
-  hipLaunchKernelGGL(sw_walk_kernel, dim3(n_pairs), dim3(64), 0, stream, d_pairs, d_outs, n_pairs,
-                     sc.match, sc.miss, sc.gap);
+  if (rpl == 4)
+    hipLaunchKernelGGL(sw_walk_kernel<4>, dim3(n_pairs), dim3(64), 0, stream, d_pairs, d_outs, n_pairs, sc.match,
+                       sc.miss, sc.gap);
+  else if (rpl == 2)
+    hipLaunchKernelGGL(sw_walk_kernel<2>, dim3(n_pairs), dim3(64), 0, stream, d_pairs, d_outs, n_pairs, sc.match,
+                       sc.miss, sc.gap);
+  else if (rpl == 1)
+    hipLaunchKernelGGL(sw_walk_kernel<1>, dim3(n_pairs), dim3(64), 0, stream, d_pairs, d_outs, n_pairs, sc.match,
+                       sc.miss, sc.gap);
+  else
+    return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

@@ -46,15 +46,16 @@ struct ExactOut {
   uint32_t bj;    // best cell, 1-based target index
   uint32_t nops;  // number of traceback ops (walker)
 };
-constexpr int kExactRPL = 4;             // rows per lane
-constexpr int kExactSH = 64 * kExactRPL; // rows per strip
+// Rows per lane (rpl) of the exact kernel: 4, 2 or 1, i.e. strips of 256, 128 or 64 query rows -- chosen per
+// submission (exact_choose_rpl): 4 does the least work per cell (batches of many pairs), smaller strips give a
+// single long pair more waves and a shorter step.
 
 // steps per strip (multiple of 16: lane 63 reaches column maxcol at step maxcol + 62) for a pair whose widest
 // row has `maxcol` columns
 __host__ __device__ inline uint32_t exact_nsteps(uint32_t maxcol) { return maxcol == 0 ? 0 : ((maxcol + 63 + 15) / 16) * 16; }
-__host__ __device__ inline uint32_t exact_nstrips(uint32_t Q) { return (Q + kExactSH - 1) / kExactSH; }
-inline size_t exact_dir_words(uint32_t Q, uint32_t maxcol) {
-  return (size_t)exact_nstrips(Q) * (exact_nsteps(maxcol) / 16) * kExactRPL * 64;
+__host__ __device__ inline uint32_t exact_nstrips(uint32_t Q, int rpl) { return (Q + 64 * rpl - 1) / (64 * rpl); }
+inline size_t exact_dir_words(uint32_t Q, uint32_t maxcol, int rpl) {
+  return (size_t)exact_nstrips(Q, rpl) * (exact_nsteps(maxcol) / 16) * rpl * 64;
 }
 
 // best cell of one strip (the last strip of a pair to finish combines them)
@@ -70,13 +71,14 @@ struct ExactWork {
   const uint32_t* unit_pair;  // per ticket: index of its pair
   uint32_t n_units;
   uint32_t n_pairs;
+  int rpl;              // rows per lane of this launch: 4, 2 or 1
   ExactRec* recs;       // per ticket
   uint32_t* pair_done;  // per pair: strips finished (zeroed)
   uint32_t* ticket;     // work counter (zeroed)
   uint32_t* err;        // != 0: a hand-over wait timed out (zeroed)
 };
 hipError_t launch_exact(const ExactWork& w, Scoring sc, hipStream_t stream);
-hipError_t launch_walk(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, Scoring sc,
+hipError_t launch_walk(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, int rpl, Scoring sc,
                        hipStream_t stream);
 
 // ---- inter-task score kernel ---------------------------------------------------------------------------

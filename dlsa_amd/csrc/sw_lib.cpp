@@ -193,7 +193,7 @@ struct PairOut {
 
 // Runs pairs [begin, end) in one submission.  Caller holds the context mutex.
 int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc, bool want_trace, PairOut* outs,
-                    std::vector<uint8_t>* arena) {
+                    std::vector<uint8_t>* arena, int rpl) {
   Context& c = g_ctx;
   const size_t n = end - begin;
   if (n == 0) return SW_OK;
@@ -228,7 +228,7 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
     const uint32_t maxcol = std::max(pp.Tlim, pp.T0);
     e.bnd_pitch = maxcol + 2;
     e.nkb = exact_nsteps(maxcol) / 16;
-    e.n_units = std::max<uint32_t>(exact_nstrips(s.Q), 1);
+    e.n_units = std::max<uint32_t>(exact_nstrips(s.Q, rpl), 1);
     if (unit_pair.size() + e.n_units > 0x7fffff00ull) return fail(SW_E_ARG, "too many strips in one submission");
     e.first_unit = (uint32_t)unit_pair.size();
     unit_pair.insert(unit_pair.end(), e.n_units, (uint32_t)i);
@@ -237,7 +237,7 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
     bnd_ints += (size_t)e.n_units * e.bnd_pitch;
     if (want_trace) {
       e.dirs = (uint32_t*)(uintptr_t)(dir_words + 1);  // +1 so that offset 0 is not nullptr
-      dir_words += exact_dir_words(s.Q, maxcol);
+      dir_words += exact_dir_words(s.Q, maxcol, rpl);
       e.ops = (uint8_t*)(uintptr_t)ops_bytes;
       ops_bytes += ((size_t)s.Q + s.T + 15) / 16 * 16;
     } else {
@@ -283,12 +283,13 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
   w.unit_pair = (const uint32_t*)c.xunits.p;
   w.n_units = (uint32_t)n_units;
   w.n_pairs = (uint32_t)n;
+  w.rpl = rpl;
   w.ticket = (uint32_t*)c.xctl.p;
   w.err = (uint32_t*)c.xctl.p + 32;
   w.pair_done = (uint32_t*)c.xctl.p + 64;
   w.recs = (ExactRec*)c.xrecs.p;
   HIPCK(launch_exact(w, sc, c.stream));
-  if (want_trace) HIPCK(launch_walk((const ExactPair*)c.pairs.p, (ExactOut*)c.outs.p, (uint32_t)n, sc, c.stream));
+  if (want_trace) HIPCK(launch_walk((const ExactPair*)c.pairs.p, (ExactOut*)c.outs.p, (uint32_t)n, rpl, sc, c.stream));
   HIPCK(hipEventRecord(c.ev3, c.stream));
   std::vector<ExactOut> ho(n);
   HIPCK(hipMemcpyAsync(ho.data(), c.outs.p, n * sizeof(ExactOut), hipMemcpyDeviceToHost, c.stream));
@@ -334,22 +335,54 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
   return SW_OK;
 }
 
+// Rows per lane for a submission.  4 does the least work per cell and is used whenever the submission fills the
+// GPU anyway (>= one wave per SIMD).  For a few long pairs the strips of a pair form a pipeline in which strip
+// s + 1 trails strip s by a fixed lag, so the time is about steps * step time + strips * lag; smaller strips
+// shorten the step (fewer rows per lane) at the price of more strips.  Step times and lags (ns) as measured on
+// MI355X with T = 100 000.
+int exact_choose_rpl(const PairSpec* specs, size_t n, int simds) {
+  static const int forced = [] {
+    const char* e = getenv("SW_HIP_EXACT_RPL");
+    const int v = e ? atoi(e) : 0;
+    return (v == 1 || v == 2 || v == 4) ? v : 0;
+  }();
+  if (forced) return forced;
+  const int rpls[3] = {4, 2, 1};
+  const double tstep[3] = {154, 104, 78}, lag[3] = {16800, 11000, 9400};
+  int best = 4;
+  double best_t = 0;
+  for (int i = 0; i < 3; i++) {
+    uint64_t waves = 0;
+    double t = 0;
+    for (size_t k = 0; k < n; k++) {
+      const uint32_t st = std::max<uint32_t>(exact_nstrips(specs[k].Q, rpls[i]), 1);
+      waves += st;
+      t = std::max(t, (double)exact_nsteps(specs[k].T) * tstep[i] + st * lag[i]);
+      if (waves > (uint64_t)simds) break;
+    }
+    if (i > 0 && waves > (uint64_t)simds) break;  // the GPU is full: stay with the larger strips
+    if (i == 0 || t < best_t) best = rpls[i], best_t = t;
+  }
+  return best;
+}
+
 int run_exact(const PairSpec* specs, size_t n, Scoring sc, bool want_trace, PairOut* outs,
               std::vector<uint8_t>* arena = nullptr) {
   Context& c = g_ctx;
+  const int rpl = exact_choose_rpl(specs, n, c.cus * 4);
   size_t begin = 0;
   while (begin < n) {
     size_t end = begin, bytes = 0;
     while (end < n) {
       PathParams pp = resolve_path(specs[end].path, specs[end].Q, specs[end].T);
       size_t b = (size_t)specs[end].Q * 2 + (size_t)specs[end].T * 2 +
-                 (size_t)std::max<uint32_t>(exact_nstrips(specs[end].Q), 1) * (specs[end].T + 2) * 4 + 256;
-      if (want_trace) b += exact_dir_words(specs[end].Q, std::max(pp.Tlim, pp.T0)) * 4 + specs[end].Q + specs[end].T;
+                 (size_t)std::max<uint32_t>(exact_nstrips(specs[end].Q, rpl), 1) * (specs[end].T + 2) * 4 + 256;
+      if (want_trace) b += exact_dir_words(specs[end].Q, std::max(pp.Tlim, pp.T0), rpl) * 4 + specs[end].Q + specs[end].T;
       if (end > begin && (bytes + b > c.scratch_budget || end - begin >= (1u << 20))) break;
       bytes += b;
       end++;
     }
-    int rc = run_exact_chunk(specs, begin, end, sc, want_trace, outs, arena);
+    int rc = run_exact_chunk(specs, begin, end, sc, want_trace, outs, arena, rpl);
     if (rc) return rc;
     begin = end;
   }
