@@ -396,14 +396,33 @@ struct ResultBox {
   uint32_t magic;
 };
 constexpr uint32_t kMagic = 0x53574850u;  // "SWHP"
-std::mutex g_str_mu;
-std::unordered_map<char*, ResultBox*> g_live_strings;  // strings still owned by a live Result
+// Result strings carry a 16-byte header in front of the characters: which Result (if any) still owns them.  That
+// is what lets free_c_string() be called on either string of a Result before free_alignment_result()
+// (SURVEY.md 8b "Ownership") without a global registry -- a work package returns 10^5 results at a time.
+struct StrHdr {
+  ResultBox* owner;  // nullptr: a stand-alone string (sw_hit)
+  uint64_t magic;
+};
+constexpr uint64_t kStrMagic = 0x5357485053545231ull;  // "SWHPSTR1"
+char* str_alloc(size_t n) {
+  StrHdr* h = (StrHdr*)malloc(sizeof(StrHdr) + n + 1);
+  if (!h) return nullptr;
+  h->owner = nullptr;
+  h->magic = kStrMagic;
+  char* p = (char*)(h + 1);
+  p[n] = 0;
+  return p;
+}
+void str_free(char* p) {
+  if (!p) return;
+  StrHdr* h = (StrHdr*)p - 1;
+  h->magic = 0;
+  free(h);
+}
 
 char* dup_string(const std::string& s) {
-  char* p = (char*)malloc(s.size() + 1);
-  if (!p) return nullptr;
-  memcpy(p, s.data(), s.size());
-  p[s.size()] = 0;
+  char* p = str_alloc(s.size());
+  if (p) memcpy(p, s.data(), s.size());
   return p;
 }
 
@@ -446,11 +465,11 @@ bool build_alignment(const Decoded& q, const Decoded& t, const PairOut& o, const
   }
   uint32_t cx = o.bx - nx, cj = o.bj - nj;  // 0-based index of the first aligned symbol
   if (q.ascii && t.ascii) {
-    char* qa = (char*)malloc((size_t)o.nops + 1);
-    char* ta = (char*)malloc((size_t)o.nops + 1);
+    char* qa = str_alloc(o.nops);
+    char* ta = str_alloc(o.nops);
     if (!qa || !ta) {
-      free(qa);
-      free(ta);
+      str_free(qa);
+      str_free(ta);
       return false;
     }
     size_t w = 0;
@@ -477,23 +496,25 @@ bool build_alignment(const Decoded& q, const Decoded& t, const PairOut& o, const
   *ta_out = dup_string(ta);
   *qa_len = qa.size();
   if (!*qa_out || !*ta_out) {
-    free(*qa_out);
-    free(*ta_out);
+    str_free(*qa_out);
+    str_free(*ta_out);
     return false;
   }
   return true;
 }
 
-// takes ownership of qa / ta; the caller registers the strings (register_results)
+// takes ownership of qa / ta (from str_alloc)
 ResultBox* box_result(char* qa, char* ta, int path, const PairOut& o) {
   ResultBox* b = (ResultBox*)calloc(1, sizeof(ResultBox));
   if (!b) {
-    free(qa);
-    free(ta);
+    str_free(qa);
+    str_free(ta);
     return nullptr;
   }
   b->r.query_ptr = qa;
   b->r.target_ptr = ta;
+  ((StrHdr*)qa - 1)->owner = b;
+  ((StrHdr*)ta - 1)->owner = b;
   b->magic = kMagic;
   if (path == SW_PATH_STRAIGHT) {  // rust/src/lib.rs:70: (.., 0, x, y)
     b->score32 = 0;
@@ -508,16 +529,6 @@ ResultBox* box_result(char* qa, char* ta, int path, const PairOut& o) {
   }
   return b;
 }
-void register_results(Result* const* res, size_t n) {
-  std::lock_guard<std::mutex> lk(g_str_mu);
-  for (size_t i = 0; i < n; i++) {
-    if (!res[i]) continue;
-    ResultBox* b = (ResultBox*)res[i];
-    g_live_strings[b->r.query_ptr] = b;
-    g_live_strings[b->r.target_ptr] = b;
-  }
-}
-
 Scoring to_scoring(AlignmentScores s) {
   return Scoring{(int)(int16_t)s.match, (int)(int16_t)s.miss, (int)(int16_t)s.gap};
 }
@@ -605,7 +616,6 @@ int align_many(const char* const* queries, const char* const* targets, size_t n,
       out[i] = b ? &b->r : nullptr;
     }
   });
-  register_results(out, n);
   return SW_OK;
 }
 
@@ -648,30 +658,24 @@ void free_alignment_result(Result* result) {
   if (!result) return;
   ResultBox* b = (ResultBox*)result;
   if (b->magic != kMagic) return;  // not ours (or already freed): leave it alone
-  {
-    std::lock_guard<std::mutex> lk(g_str_mu);
-    if (b->r.query_ptr) g_live_strings.erase(b->r.query_ptr);
-    if (b->r.target_ptr) g_live_strings.erase(b->r.target_ptr);
-  }
-  free(b->r.query_ptr);
-  free(b->r.target_ptr);
+  str_free(b->r.query_ptr);        // (a string handed to free_c_string earlier has been detached: nullptr)
+  str_free(b->r.target_ptr);
   b->magic = 0;
   free(b);
 }
 
 void free_c_string(char* str) {
   if (!str) return;
-  {
-    std::lock_guard<std::mutex> lk(g_str_mu);
-    auto it = g_live_strings.find(str);
-    if (it != g_live_strings.end()) {  // detach from its Result so free_alignment_result will not free it again
-      ResultBox* b = it->second;
-      if (b->r.query_ptr == str) b->r.query_ptr = nullptr;
-      if (b->r.target_ptr == str) b->r.target_ptr = nullptr;
-      g_live_strings.erase(it);
-    }
+  StrHdr* h = (StrHdr*)str - 1;
+  if (h->magic != kStrMagic) {  // not one of ours: the reference would hand it to CString::from_raw all the same
+    free(str);
+    return;
   }
-  free(str);
+  if (ResultBox* b = h->owner) {  // detach from its Result so free_alignment_result will not free it again
+    if (b->r.query_ptr == str) b->r.query_ptr = nullptr;
+    if (b->r.target_ptr == str) b->r.target_ptr = nullptr;
+  }
+  str_free(str);
 }
 
 // ================================================================================================
@@ -1344,8 +1348,8 @@ int sw_db_search_topk_batch(sw_db* db, const char* const* queries, size_t n_quer
       size_t qlen = 0;
       const bool built = build_alignment(qps[q].d, tdec[at], po[at], arena.data() + po[at].ops_off, &qa, &ta, &qlen);
       if (!built || po[at].score != e.score) {
-        free(qa);
-        free(ta);
+        str_free(qa);
+        str_free(ta);
         for (size_t r = 0; r < n_queries; r++) {
           sw_hits_free(hits + r * (size_t)k, n_hits[r]);
           n_hits[r] = 0;
@@ -1376,8 +1380,8 @@ int sw_db_search_topk(sw_db* db, const char* query, AlignmentScores as, int k, s
 void sw_hits_free(sw_hit* hits, int n_hits) {
   if (!hits) return;
   for (int i = 0; i < n_hits; i++) {
-    free(hits[i].query_aln);
-    free(hits[i].target_aln);
+    str_free(hits[i].query_aln);
+    str_free(hits[i].target_aln);
     hits[i].query_aln = hits[i].target_aln = nullptr;
   }
 }
