@@ -1071,6 +1071,13 @@ bool needs_exact(uint32_t T, int32_t s, uint32_t Q, uint32_t Qp, Scoring sc) {
   return false;
 }
 
+// The database path answers what the WORKER would have got for the pair, i.e. the fallback chain of
+// worker_impl.go:170-202: find_alignment_low_memory, or find_alignment_simd where that one panics (gap == 0 on
+// the ring path, rust/src/algorithm/mod.rs:236-238).
+int db_pair_path(uint32_t Q, uint32_t T, Scoring sc) {
+  return ring_div_by_zero(SW_PATH_LOW_MEMORY, Q, T, sc) ? SW_PATH_SIMD : SW_PATH_LOW_MEMORY;
+}
+
 // exact (int32, score only) re-run of a list of database targets
 int rescore_locked(sw_db* db, const QueryPrep& qp, Scoring sc, const std::vector<uint32_t>& rerun,
                    std::vector<int32_t>& out) {
@@ -1083,7 +1090,8 @@ int rescore_locked(sw_db* db, const QueryPrep& qp, Scoring sc, const std::vector
     uint32_t ti = rerun[k];
     // (valid UTF-8: checked when the database was built)
     decode(db->flat.data() + db->off[ti], (size_t)(db->off[ti + 1] - db->off[ti]), tdec[k]);
-    specs[k] = PairSpec{qp.d.sym.data(), Q, tdec[k].sym.data(), (uint32_t)tdec[k].sym.size(), SW_PATH_LOW_MEMORY};
+    specs[k] = PairSpec{qp.d.sym.data(), Q, tdec[k].sym.data(), (uint32_t)tdec[k].sym.size(),
+                        db_pair_path(Q, (uint32_t)tdec[k].sym.size(), sc)};
   }
   std::vector<PairOut> po(rerun.size());
   int rc = run_exact(specs.data(), specs.size(), sc, false, po.data());
@@ -1333,7 +1341,8 @@ int sw_db_search_topk_batch(sw_db* db, const char* const* queries, size_t n_quer
       for (const TopEntry& e : tops[q]) {
         decode(db->flat.data() + db->off[e.target], (size_t)(db->off[e.target + 1] - db->off[e.target]), tdec[at]);
         specs.push_back(PairSpec{qps[q].d.sym.data(), (uint32_t)qps[q].d.sym.size(), tdec[at].sym.data(),
-                                 (uint32_t)tdec[at].sym.size(), SW_PATH_LOW_MEMORY});
+                                 (uint32_t)tdec[at].sym.size(),
+                                 db_pair_path((uint32_t)qps[q].d.sym.size(), (uint32_t)tdec[at].sym.size(), sc)});
         at++;
       }
     po.resize(total);

@@ -81,8 +81,10 @@ struct sw_hit {
   char *target_aln;
 };
 
-/* Scores `query` against every database sequence with find_alignment_low_memory semantics and returns
- * the k best hits with full alignments.  *n_hits <= k.  Exact for every reported field. */
+/* Scores `query` against every database sequence with the semantics the worker sees for a pair -- the fallback
+ * chain of worker_impl.go:170-202: find_alignment_low_memory, or find_alignment_simd where that one fails (gap == 0
+ * on the ring path) -- and returns the k best hits with full alignments.  *n_hits <= k.  Exact for every
+ * reported field. */
 int sw_db_search_topk(sw_db *db, const char *query, struct AlignmentScores scores, int k,
                       struct sw_hit *hits, int *n_hits);
 /* The same for n_queries queries in one call: what a work package of the reference holds (many queries against

@@ -201,3 +201,35 @@ def test_device_topk_tie_list_overflow_falls_back(oracle):
         assert (hits[1]["score"], hits[1]["query_aln"], hits[1]["target_aln"]) == (e["score"], e["q"], e["t"])
     finally:
         db.close()
+
+
+@pytest.mark.parametrize("sc", [(-2, 1, -1), (-1, 1, -3), (-4, 3, -1), (-1, 7, -2), (0, 2, -1), (-1, 2, 0)])
+def test_other_scorings_like_the_worker_fallback_chain(oracle, sc):
+    """Scorings besides match 2 / mismatch 1 / gap 1: the capacity benchmark's (worker_rust_benchmark.go:10-18), steep
+    and flat penalties, and two outside the packed kernel's domain (gap 0: the ring path panics in the reference and
+    the worker falls back to find_alignment_simd; mismatch 0).  Expected = the oracle's fallback chain per pair."""
+    import dlsa_amd
+    from dlsa_amd import bridge
+    rng = random.Random(hash(sc) & 0xFFFF)
+    gap, match, miss = sc
+    q = _rnd(rng, 150)
+    targets = [_rnd(rng, rng.choice([rng.randint(1, 280), 64, 128, 320, 640])) for _ in range(260)]
+    targets[3] = targets[3][:15] + q[20:120] + targets[3][15:40]
+    targets[200] = q[:60] + "T" + q[60:]
+    s = dlsa_amd.AlignmentScore(match, miss, gap)
+    exp = [oracle.align_with_fallback(q, t, gap, match, miss) for t in targets]
+    assert all(e is not None for e in exp)
+    db = bridge.Database(seqs=targets)
+    try:
+        got = db.scores(q, s)
+        bad = [(i, int(got[i]), exp[i]["score"], len(targets[i])) for i in range(len(targets)) if int(got[i]) != exp[i]["score"]]
+        assert not bad, bad[:10]
+        hits = db.search_topk(q, s, 6)
+        order = sorted(range(len(exp)), key=lambda i: (-exp[i]["score"], i))[:6]
+        assert [h["target_index"] for h in hits] == order
+        for h, i in zip(hits, order):
+            e = exp[i]
+            assert (h["score"], h["max_x"], h["max_y"], h["query_aln"], h["target_aln"]) == (
+                e["score"], e["max_x"], e["max_y"], e["q"], e["t"]), (i, len(targets[i]))
+    finally:
+        db.close()
