@@ -10,6 +10,7 @@
 #include <array>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -65,6 +66,23 @@ struct DevBuf {
   }
 };
 
+// pinned host staging memory (async copies from pageable memory are staged by the runtime, synchronously)
+struct HostBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return SW_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess)
+      return fail(SW_E_NOMEM, std::string("hipHostMalloc(") + std::to_string(want) + ") failed");
+    cap = want;
+    return SW_OK;
+  }
+};
+
 struct Context {
   std::mutex mu;  // one GPU submission at a time; the ABI is entered from many threads
   bool ready = false;
@@ -72,8 +90,8 @@ struct Context {
   int cus = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
-  DevBuf sym, pairs, outs, dirs, bnd, ops;            // exact path scratch
-  DevBuf xunits, xctl, xrecs;                          // exact path: ticket table, control words, strip records
+  DevBuf xin, xzero, xout, dirs, xrecs;                // exact path scratch (run_exact_chunk)
+  HostBuf h_in, h_out;                                 // ... and its pinned staging buffers
   DevBuf sel_hist, sel_ctr, sel_rerun, sel_cand, sel_tie;  // device-side top-k selection
   DevBuf qwords, slot_scores, gbound, ticket, prog;    // score path scratch
   sw_kernel_stats stats{};
@@ -246,54 +264,66 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
     }
   }
   const size_t n_units = unit_pair.size();
-  // control words: [0] ticket, [32] err, [64 ..) per-pair done counters
+  // One blob each way (a per-pair call is dominated by the number of HIP calls, not by bytes):
+  //   xin   (H2D):   [ExactPair x n | unit_pair x n_units | symbols]      staged in pinned host memory
+  //   xzero (memset): [control words: [0] ticket, [32] err, [64 ..) per-pair done counters | boundary rows]
+  //   xout  (D2H):   [ExactOut x n | traceback ops]
+  auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  const size_t in_pairs = 0, in_units = align16(n * sizeof(ExactPair)), in_sym = in_units + align16(n_units * 4);
+  const size_t in_bytes = in_sym + align16(pool.size() * 2 + 16);
   const size_t ctl_words = 64 + n;
+  const size_t z_bnd = align16(ctl_words * 4), z_bytes = z_bnd + align16(std::max<size_t>(bnd_ints * 4, 16));
+  const size_t out_ops = align16(n * sizeof(ExactOut)), out_bytes = out_ops + (want_trace ? align16(ops_bytes) : 0);
   int rc;
-  if ((rc = c.sym.ensure(std::max<size_t>(pool.size() * 2, 16)))) return rc;
-  if ((rc = c.pairs.ensure(n * sizeof(ExactPair)))) return rc;
-  if ((rc = c.outs.ensure(n * sizeof(ExactOut)))) return rc;
-  if ((rc = c.bnd.ensure(std::max<size_t>(bnd_ints * 4, 16)))) return rc;
-  if ((rc = c.xunits.ensure(n_units * 4))) return rc;
-  if ((rc = c.xctl.ensure(ctl_words * 4))) return rc;
+  if ((rc = c.xin.ensure(in_bytes))) return rc;
+  if ((rc = c.xzero.ensure(z_bytes))) return rc;
+  if ((rc = c.xout.ensure(out_bytes))) return rc;
   if ((rc = c.xrecs.ensure(n_units * sizeof(ExactRec)))) return rc;
-  if (want_trace) {
-    if ((rc = c.dirs.ensure(std::max<size_t>(dir_words * 4, 16)))) return rc;
-    if ((rc = c.ops.ensure(std::max<size_t>(ops_bytes, 16)))) return rc;
-  }
+  if (want_trace && (rc = c.dirs.ensure(std::max<size_t>(dir_words * 4, 16)))) return rc;
+  if ((rc = c.h_in.ensure(in_bytes))) return rc;
+  uint8_t* const d_in = (uint8_t*)c.xin.p;
+  uint8_t* const d_zero = (uint8_t*)c.xzero.p;
+  uint8_t* const d_out = (uint8_t*)c.xout.p;
   for (size_t i = 0; i < n; i++) {
     ExactPair& e = hp[i];
-    e.q = (const uint16_t*)c.sym.p + qoff[i];
-    e.t = (const uint16_t*)c.sym.p + toff[i];
-    e.bnd = (int32_t*)c.bnd.p + (uintptr_t)e.bnd;
+    e.q = (const uint16_t*)(d_in + in_sym) + qoff[i];
+    e.t = (const uint16_t*)(d_in + in_sym) + toff[i];
+    e.bnd = (int32_t*)(d_zero + z_bnd) + (uintptr_t)e.bnd;
     if (want_trace) {
       e.dirs = (uint32_t*)c.dirs.p + ((uintptr_t)e.dirs - 1);
-      e.ops = (uint8_t*)c.ops.p + (uintptr_t)e.ops;
+      e.ops = d_out + out_ops + (uintptr_t)e.ops;
     }
   }
-  if (!pool.empty()) HIPCK(hipMemcpyAsync(c.sym.p, pool.data(), pool.size() * 2, hipMemcpyHostToDevice, c.stream));
-  HIPCK(hipMemcpyAsync(c.pairs.p, hp.data(), n * sizeof(ExactPair), hipMemcpyHostToDevice, c.stream));
-  HIPCK(hipMemcpyAsync(c.xunits.p, unit_pair.data(), n_units * 4, hipMemcpyHostToDevice, c.stream));
-  HIPCK(hipMemsetAsync(c.xctl.p, 0, ctl_words * 4, c.stream));
-  // strip boundary rows: a word is "published" when its bit 31 is set (sw_exact.hip), so they start at zero
-  HIPCK(hipMemsetAsync(c.bnd.p, 0, std::max<size_t>(bnd_ints * 4, 16), c.stream));
+  uint8_t* const h_in = (uint8_t*)c.h_in.p;
+  memcpy(h_in + in_pairs, hp.data(), n * sizeof(ExactPair));
+  memcpy(h_in + in_units, unit_pair.data(), n_units * 4);
+  if (!pool.empty()) memcpy(h_in + in_sym, pool.data(), pool.size() * 2);
+  HIPCK(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, c.stream));
+  // (strip boundary rows: a word is "published" when its bit 31 is set (sw_exact.hip), so they start at zero)
+  HIPCK(hipMemsetAsync(d_zero, 0, z_bytes, c.stream));
   HIPCK(hipEventRecord(c.ev2, c.stream));
   ExactWork w{};
-  w.pairs = (const ExactPair*)c.pairs.p;
-  w.outs = (ExactOut*)c.outs.p;
-  w.unit_pair = (const uint32_t*)c.xunits.p;
+  w.pairs = (const ExactPair*)(d_in + in_pairs);
+  w.outs = (ExactOut*)d_out;
+  w.unit_pair = (const uint32_t*)(d_in + in_units);
   w.n_units = (uint32_t)n_units;
   w.n_pairs = (uint32_t)n;
   w.rpl = rpl;
-  w.ticket = (uint32_t*)c.xctl.p;
-  w.err = (uint32_t*)c.xctl.p + 32;
-  w.pair_done = (uint32_t*)c.xctl.p + 64;
+  w.ticket = (uint32_t*)d_zero;
+  w.err = (uint32_t*)d_zero + 32;
+  w.pair_done = (uint32_t*)d_zero + 64;
   w.recs = (ExactRec*)c.xrecs.p;
   HIPCK(launch_exact(w, sc, c.stream));
-  if (want_trace) HIPCK(launch_walk((const ExactPair*)c.pairs.p, (ExactOut*)c.outs.p, (uint32_t)n, rpl, sc, c.stream));
+  if (want_trace) HIPCK(launch_walk(w.pairs, w.outs, (uint32_t)n, rpl, sc, c.stream));
   HIPCK(hipEventRecord(c.ev3, c.stream));
-  std::vector<ExactOut> ho(n);
-  HIPCK(hipMemcpyAsync(ho.data(), c.outs.p, n * sizeof(ExactOut), hipMemcpyDeviceToHost, c.stream));
+  // small submissions fetch results and ops in ONE copy (the ops capacity is Q + T per pair); big ones fetch the
+  // results first and then only the op bytes the walkers wrote
+  const bool one_copy = want_trace && out_bytes <= ((size_t)4 << 20);
+  const size_t first_bytes = one_copy ? out_bytes : n * sizeof(ExactOut);
+  if ((rc = c.h_out.ensure(first_bytes))) return rc;
+  HIPCK(hipMemcpyAsync(c.h_out.p, d_out, first_bytes, hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipStreamSynchronize(c.stream));
+  const ExactOut* ho = (const ExactOut*)c.h_out.p;
   for (size_t i = 0; i < n; i++)
     if (ho[i].nops == 0xffffffffu) return fail(SW_E_HIP, "exact kernel: strip pipeline wait timed out");
   float ms = 0;
@@ -301,25 +331,31 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
   c.stats.exact_kernel_ms += ms;
   size_t arena_base = 0;
   if (want_trace && ops_bytes) {
-    // copy only what the walkers wrote, straight into the caller's arena
     arena_base = arena->size();
     arena->resize(arena_base + ops_bytes);
     uint8_t* hops = arena->data() + arena_base;
-    size_t lo = 0;
-    while (lo < n) {  // coalesce into a few large copies: ops buffers are contiguous per pair
-      size_t hi = lo;
-      size_t start = (uint8_t*)hp[lo].ops - (uint8_t*)c.ops.p;
-      size_t endb = start;
-      while (hi < n) {
-        size_t s0 = (uint8_t*)hp[hi].ops - (uint8_t*)c.ops.p;
-        if (s0 - endb > (1u << 16)) break;
-        endb = s0 + ho[hi].nops;
-        hi++;
+    if (one_copy) {
+      for (size_t i = 0; i < n; i++) {
+        const size_t s0 = (size_t)(hp[i].ops - (d_out + out_ops));
+        if (ho[i].nops) memcpy(hops + s0, (const uint8_t*)c.h_out.p + out_ops + s0, ho[i].nops);
       }
-      if (endb > start) HIPCK(hipMemcpyAsync(hops + start, (uint8_t*)c.ops.p + start, endb - start, hipMemcpyDeviceToHost, c.stream));
-      lo = hi;
+    } else {
+      size_t lo = 0;
+      while (lo < n) {  // coalesce into a few large copies: ops buffers are contiguous per pair
+        size_t hi = lo;
+        size_t start = (size_t)(hp[lo].ops - (d_out + out_ops));
+        size_t endb = start;
+        while (hi < n) {
+          size_t s0 = (size_t)(hp[hi].ops - (d_out + out_ops));
+          if (s0 - endb > (1u << 16)) break;
+          endb = s0 + ho[hi].nops;
+          hi++;
+        }
+        if (endb > start) HIPCK(hipMemcpyAsync(hops + start, d_out + out_ops + start, endb - start, hipMemcpyDeviceToHost, c.stream));
+        lo = hi;
+      }
+      HIPCK(hipStreamSynchronize(c.stream));
     }
-    HIPCK(hipStreamSynchronize(c.stream));
   }
   for (size_t i = 0; i < n; i++) {
     PairOut& o = outs[begin + i];
@@ -328,7 +364,7 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
     o.bj = ho[i].bj;
     c.stats.exact_cells += (uint64_t)specs[begin + i].Q * specs[begin + i].T;
     if (want_trace && ho[i].nops) {
-      o.ops_off = arena_base + (size_t)((uint8_t*)hp[i].ops - (uint8_t*)c.ops.p);
+      o.ops_off = arena_base + (size_t)(hp[i].ops - (d_out + out_ops));
       o.nops = ho[i].nops;
     }
   }
@@ -619,14 +655,95 @@ int align_many(const char* const* queries, const char* const* targets, size_t n,
   return SW_OK;
 }
 
+// ---- one pair per call, many callers: combining ---------------------------------------------------------------
+// The Go worker enters the drop-in ABI from NumCPU-1 goroutines, one pair per call (worker_impl.go:204-238).  A GPU
+// round trip costs a few hundred microseconds whatever the batch size, so concurrent callers are COMBINED: a caller
+// that finds no submission in flight becomes the leader and submits everything that has queued up (its own request
+// included) as one batch; the others sleep until their result is there.  A leader steps down once its own request
+// is done, and a waiter whose request is still queued takes over.  Results are identical to one call per pair
+// (align_many computes every pair independently); with a single caller this is exactly the old path.
+struct OneReq {
+  const char* q;
+  const char* t;
+  AlignmentScores as;
+  int path;
+  Result* out = nullptr;
+  int rc = SW_OK;
+  std::string err;
+  bool done = false;
+};
+std::mutex g_comb_mu;
+std::condition_variable g_comb_cv;
+std::vector<OneReq*> g_comb_pending;
+bool g_comb_leader = false;
+size_t g_comb_expect = 1;  // how many concurrent callers recent batches have seen (decays)
+
+void combine_run_batch(std::vector<OneReq*>& batch) {
+  // group by (scores, path): one submission per group (a worker uses one scoring per work package)
+  std::vector<char> taken(batch.size(), 0);
+  for (size_t i = 0; i < batch.size(); i++) {
+    if (taken[i]) continue;
+    std::vector<size_t> grp;
+    for (size_t k = i; k < batch.size(); k++)
+      if (!taken[k] && batch[k]->path == batch[i]->path && memcmp(&batch[k]->as, &batch[i]->as, sizeof(AlignmentScores)) == 0) {
+        taken[k] = 1;
+        grp.push_back(k);
+      }
+    std::vector<const char*> qs(grp.size()), ts(grp.size());
+    std::vector<Result*> out(grp.size(), nullptr);
+    for (size_t k = 0; k < grp.size(); k++) {
+      qs[k] = batch[grp[k]]->q;
+      ts[k] = batch[grp[k]]->t;
+    }
+    g_err.clear();
+    const int rc = align_many(qs.data(), ts.data(), grp.size(), batch[i]->as, batch[i]->path, out.data());
+    for (size_t k = 0; k < grp.size(); k++) {
+      OneReq* r = batch[grp[k]];
+      r->rc = rc;
+      r->out = rc == SW_OK ? out[k] : nullptr;
+      if (!r->out) r->err = rc != SW_OK ? g_err : std::string("invalid input (UTF-8) or reference panic condition");
+    }
+  }
+}
+
 Result* align_one(char* query, char* target, AlignmentScores as, int path) {
-  Result* r = nullptr;
-  const char* q = query;
-  const char* t = target;
-  int rc = align_many(&q, &t, 1, as, path, &r);
-  if (rc != SW_OK) return nullptr;
-  if (!r && g_err.empty()) g_err = "invalid input (UTF-8) or reference panic condition";
-  return r;
+  OneReq me;
+  me.q = query;
+  me.t = target;
+  me.as = as;
+  me.path = path;
+  std::unique_lock<std::mutex> lk(g_comb_mu);
+  g_comb_pending.push_back(&me);
+  if (g_comb_leader) g_comb_cv.notify_all();  // a leader may be gathering
+  while (!me.done) {
+    if (g_comb_leader) {
+      g_comb_cv.wait(lk);
+      continue;
+    }
+    g_comb_leader = true;  // lead until my own request has been served
+    while (!me.done) {
+      // Callers released by the previous batch are on their way back with their next pair: give them a moment
+      // (bounded, a fraction of a GPU round trip) instead of submitting a batch of two.
+      if (g_comb_pending.size() < g_comb_expect) {
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(150);
+        while (g_comb_pending.size() < g_comb_expect && std::chrono::steady_clock::now() < deadline)
+          g_comb_cv.wait_for(lk, std::chrono::microseconds(25));
+      }
+      std::vector<OneReq*> batch;
+      batch.swap(g_comb_pending);
+      g_comb_expect = std::max(batch.size(), g_comb_expect - (g_comb_expect + 3) / 4);
+      lk.unlock();
+      combine_run_batch(batch);
+      lk.lock();
+      for (OneReq* r : batch) r->done = true;
+      g_comb_cv.notify_all();
+    }
+    g_comb_leader = false;
+    g_comb_cv.notify_all();  // a waiter whose request is still queued takes over
+  }
+  lk.unlock();
+  if (!me.out) g_err = me.err;
+  return me.out;
 }
 
 }  // namespace
