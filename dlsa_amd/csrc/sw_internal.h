@@ -122,11 +122,12 @@ struct ScoreParams {
   uint32_t* prog;             // 2 per unit: boundary blocks published / input slot released (zeroed)
   uint32_t* ticket;           // work counter (zeroed before launch)
   uint32_t* err;              // set != 0 if a dependency wait timed out (zeroed before launch)
+  uint32_t pub;               // blocks per publication of an inter-unit boundary column
   int match, miss, gap;
 };
-hipError_t launch_score(const ScoreParams& p, int n_workgroups, hipStream_t stream);
-int score_waves_per_group();
-int score_workgroups_per_cu();
+hipError_t launch_score(const ScoreParams& p, int n_workgroups, int waves, hipStream_t stream);
+int score_waves_per_group(uint32_t total_strips, int cus);  // waves per workgroup for a database of that many strips
+int score_workgroups_per_cu(int waves);
 uint32_t score_queue_depth();  // units a workgroup may have in flight
 
 

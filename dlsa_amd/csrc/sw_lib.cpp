@@ -855,7 +855,7 @@ struct sw_db {
   uint32_t n_elems = 0;              // strips in the stream
   // ticket-ordered unit table, rebuilt when the interleave / ring geometry of a search differs (build_units)
   ScoreUnit* d_units = nullptr;
-  uint32_t n_units = 0, units_S = 0, units_R = 0;
+  uint32_t n_units = 0, units_S = 0, units_R = 0, units_W = 0;
   std::vector<uint32_t> generic;  // targets scored by the exact kernel only
   uint32_t max_len = 0;
 };
@@ -1109,15 +1109,15 @@ int score_pass_locked(sw_db* db, const QueryPrep& qp, Scoring sc) {
   const uint32_t Q = (uint32_t)qp.d.sym.size();
   const uint32_t nblk = (Q + kScoreB - 1) / kScoreB;
   const size_t Qpad = (size_t)nblk * kScoreB;
-  const uint32_t W = (uint32_t)score_waves_per_group();
-  const uint32_t max_wg = (uint32_t)c.cus * (uint32_t)score_workgroups_per_cu();
+  const uint32_t W = (uint32_t)score_waves_per_group(db->n_elems, c.cus);
+  const uint32_t max_wg = (uint32_t)c.cus * (uint32_t)score_workgroups_per_cu((int)W);
   // interleave: a unit should be handed out about 40 blocks after the unit it continues, i.e. when that
   // one's last wave is publishing; max_wg workgroups draw max_wg tickets per (nblk + drain) blocks
   const uint32_t S = std::min<uint32_t>(1024, std::max<uint32_t>(8, max_wg * 40 / (nblk + 16)));
   // boundary ring: a workgroup has at most 1 + queue depth units in flight, fewer when a unit is long
   const uint32_t ahead = std::min<uint32_t>(score_queue_depth(), 48 / nblk + 1);
   const uint32_t ring_slots = S + max_wg * (1 + ahead) + 8;
-  if (db->units_S != S || db->units_R != ring_slots || !db->d_units) {
+  if (db->units_S != S || db->units_R != ring_slots || db->units_W != W || !db->d_units) {
     std::vector<ScoreUnit> units;
     build_units(db, W, S, ring_slots, units);
     if (db->d_units) (void)hipFree(db->d_units);
@@ -1128,6 +1128,7 @@ int score_pass_locked(sw_db* db, const QueryPrep& qp, Scoring sc) {
     db->n_units = (uint32_t)units.size();
     db->units_S = S;
     db->units_R = ring_slots;
+    db->units_W = W;
   }
   const int nwg = (int)std::min<uint32_t>(db->n_units, max_wg);
   const size_t gb_stride = Qpad * 64;
@@ -1160,8 +1161,11 @@ int score_pass_locked(sw_db* db, const QueryPrep& qp, Scoring sc) {
   p.match = sc.match;
   p.miss = sc.miss;
   p.gap = sc.gap;
+  // a small database is a few chains of units: publish their boundary columns often (latency), a big one rarely
+  p.pub = W == 4 ? 2 : 8;
+  if (const char* e = getenv("SW_HIP_SCORE_PUB")) p.pub = std::max(1, atoi(e));  // experiments
   HIPCK(hipEventRecord(c.ev0, c.stream));
-  HIPCK(launch_score(p, nwg, c.stream));
+  HIPCK(launch_score(p, nwg, (int)W, c.stream));
   HIPCK(hipEventRecord(c.ev1, c.stream));
   return SW_OK;
 }
