@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(64) sw_exact_kernel(ExactWork W, int match, in
 // symbols and the matching target range in LDS and walks inside it with wave-uniform (scalar) state; within a
 // strip the step index k = j - 1 + lane(row) never increases along the walk, so a window is left only downwards
 // or when the path crosses into the strip above.
-constexpr uint32_t WKB = 8;  // 16-step blocks per window
+constexpr uint32_t WKB = 16;  // 16-step blocks per window
 template <int RPL>
 __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, ExactOut* outs, uint32_t n,
                                                      int match, int miss, int gap) {
