@@ -201,6 +201,9 @@ struct PairSpec {
   const uint16_t* t;
   uint32_t T;
   int path;
+  // optional: small dense ids of the two sequences within the submission (equal id <=> same sequence); lets the
+  // driver upload every distinct sequence once without hashing 10^5 pointers.  UINT32_MAX: look the pointer up.
+  uint32_t qid = UINT32_MAX, tid = UINT32_MAX;
 };
 struct PairOut {
   int32_t score = 0;
@@ -209,32 +212,61 @@ struct PairOut {
   uint32_t nops = 0;
 };
 
+// SW_HIP_TRACE=1: host stage times of big submissions on stderr (development aid)
+struct StageTimer {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  explicit StageTimer(size_t n) : on(n >= 1000 && getenv("SW_HIP_TRACE")), t0(std::chrono::steady_clock::now()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sw_hip] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
 // Runs pairs [begin, end) in one submission.  Caller holds the context mutex.
 int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc, bool want_trace, PairOut* outs,
                     std::vector<uint8_t>* arena, int rpl) {
   Context& c = g_ctx;
   const size_t n = end - begin;
   if (n == 0) return SW_OK;
-  // symbol pool, deduplicated by host pointer (a database search shares one query)
+  StageTimer tm(n);
+  // symbol pool: every distinct sequence once (a database search shares one query)
   std::unordered_map<const uint16_t*, size_t> seen;
-  std::vector<uint16_t> pool;
-  auto add_seq = [&](const uint16_t* p, uint32_t len) -> size_t {
-    auto it = seen.find(p);
-    if (it != seen.end()) return it->second;
-    size_t off = pool.size();
-    pool.insert(pool.end(), p, p + len);
-    if (pool.size() & 1) pool.push_back(0);
-    seen.emplace(p, off);
+  std::vector<size_t> off_by_id;
+  struct SeqCopy {
+    const uint16_t* p;
+    uint32_t len;
+    size_t off;
+  };
+  std::vector<SeqCopy> copies;  // distinct sequences, copied straight into the pinned staging buffer below
+  size_t pool_syms = 0;
+  auto add_seq = [&](const uint16_t* p, uint32_t len, uint32_t id) -> size_t {
+    if (id != UINT32_MAX) {
+      if (id >= off_by_id.size()) off_by_id.resize((size_t)id + 1 + off_by_id.size() / 2, SIZE_MAX);
+      if (off_by_id[id] != SIZE_MAX) return off_by_id[id];
+    } else {
+      auto it = seen.find(p);
+      if (it != seen.end()) return it->second;
+    }
+    const size_t off = pool_syms;
+    copies.push_back(SeqCopy{p, len, off});
+    pool_syms += (len + 1u) & ~(size_t)1;
+    if (id != UINT32_MAX) off_by_id[id] = off;
+    else seen.emplace(p, off);
     return off;
   };
   std::vector<ExactPair> hp(n);
   std::vector<size_t> qoff(n), toff(n);
   size_t dir_words = 0, bnd_ints = 0, ops_bytes = 0;
   std::vector<uint32_t> unit_pair;
+  unit_pair.reserve(n);
+  copies.reserve(n + 1);
   for (size_t i = 0; i < n; i++) {
     const PairSpec& s = specs[begin + i];
-    qoff[i] = add_seq(s.q, s.Q);
-    toff[i] = add_seq(s.t, s.T);
+    qoff[i] = add_seq(s.q, s.Q, s.qid);
+    toff[i] = add_seq(s.t, s.T, s.tid);
     PathParams pp = resolve_path(s.path, s.Q, s.T);
     ExactPair& e = hp[i];
     e.Q = s.Q;
@@ -263,6 +295,7 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
       e.ops = nullptr;
     }
   }
+  tm.lap("  chunk: tables");
   const size_t n_units = unit_pair.size();
   // One blob each way (a per-pair call is dominated by the number of HIP calls, not by bytes):
   //   xin   (H2D):   [ExactPair x n | unit_pair x n_units | symbols]      staged in pinned host memory
@@ -270,7 +303,7 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
   //   xout  (D2H):   [ExactOut x n | traceback ops]
   auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
   const size_t in_pairs = 0, in_units = align16(n * sizeof(ExactPair)), in_sym = in_units + align16(n_units * 4);
-  const size_t in_bytes = in_sym + align16(pool.size() * 2 + 16);
+  const size_t in_bytes = in_sym + align16(pool_syms * 2 + 16);
   const size_t ctl_words = 64 + n;
   const size_t z_bnd = align16(ctl_words * 4), z_bytes = z_bnd + align16(std::max<size_t>(bnd_ints * 4, 16));
   const size_t out_ops = align16(n * sizeof(ExactOut)), out_bytes = out_ops + (want_trace ? align16(ops_bytes) : 0);
@@ -297,7 +330,8 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
   uint8_t* const h_in = (uint8_t*)c.h_in.p;
   memcpy(h_in + in_pairs, hp.data(), n * sizeof(ExactPair));
   memcpy(h_in + in_units, unit_pair.data(), n_units * 4);
-  if (!pool.empty()) memcpy(h_in + in_sym, pool.data(), pool.size() * 2);
+  for (const SeqCopy& sc_ : copies) memcpy(h_in + in_sym + sc_.off * 2, sc_.p, (size_t)sc_.len * 2);
+  tm.lap("  chunk: stage");
   HIPCK(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, c.stream));
   // (strip boundary rows: a word is "published" when its bit 31 is set (sw_exact.hip), so they start at zero)
   HIPCK(hipMemsetAsync(d_zero, 0, z_bytes, c.stream));
@@ -324,6 +358,7 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
   HIPCK(hipMemcpyAsync(c.h_out.p, d_out, first_bytes, hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipStreamSynchronize(c.stream));
   const ExactOut* ho = (const ExactOut*)c.h_out.p;
+  tm.lap("  chunk: gpu");
   for (size_t i = 0; i < n; i++)
     if (ho[i].nops == 0xffffffffu) return fail(SW_E_HIP, "exact kernel: strip pipeline wait timed out");
   float ms = 0;
@@ -368,6 +403,7 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
       o.nops = ho[i].nops;
     }
   }
+  tm.lap("  chunk: results");
   return SW_OK;
 }
 
@@ -591,6 +627,7 @@ void parallel_ranges(size_t n, size_t work, F&& f) {
 int align_many(const char* const* queries, const char* const* targets, size_t n, AlignmentScores as, int path,
                Result** out) {
   if (n == 0) return SW_OK;
+  StageTimer tm(n);
   if (!queries || !targets || !out) return fail(SW_E_ARG, "null argument");
   if (path < 0 || path > 2) return fail(SW_E_ARG, "bad path");
   const Scoring sc = to_scoring(as);
@@ -613,6 +650,7 @@ int align_many(const char* const* queries, const char* const* targets, size_t n,
     qi[i] = intern(queries[i]);
     ti[i] = intern(targets[i]);
   }
+  tm.lap("intern");
   std::vector<Decoded> dec(distinct.size());
   std::vector<uint8_t> ok(distinct.size(), 0);
   std::vector<size_t> lens(distinct.size());
@@ -622,6 +660,7 @@ int align_many(const char* const* queries, const char* const* targets, size_t n,
     for (size_t d = lo; d < hi; d++)  // bindings.rs:125 unwrap: invalid UTF-8 -> NULL
       ok[d] = decode(distinct[d], lens[d], dec[d]) && dec[d].sym.size() < 0x7fffff00u;
   });
+  tm.lap("decode");
   std::vector<PairSpec> specs;
   std::vector<size_t> idx;
   specs.reserve(n);
@@ -630,11 +669,12 @@ int align_many(const char* const* queries, const char* const* targets, size_t n,
     if (qi[i] == UINT32_MAX || ti[i] == UINT32_MAX || !ok[qi[i]] || !ok[ti[i]]) continue;
     const Decoded &q = dec[qi[i]], &t = dec[ti[i]];
     if (ring_div_by_zero(path, (uint32_t)q.sym.size(), (uint32_t)t.sym.size(), sc)) continue;
-    specs.push_back(PairSpec{q.sym.data(), (uint32_t)q.sym.size(), t.sym.data(), (uint32_t)t.sym.size(), path});
+    specs.push_back(PairSpec{q.sym.data(), (uint32_t)q.sym.size(), t.sym.data(), (uint32_t)t.sym.size(), path, qi[i], ti[i]});
     idx.push_back(i);
   }
   std::vector<PairOut> po(specs.size());
   std::vector<uint8_t> arena;
+  tm.lap("specs");
   {
     std::lock_guard<std::mutex> lk(g_ctx.mu);
     int rc = ctx_init_locked(-1);
@@ -642,6 +682,7 @@ int align_many(const char* const* queries, const char* const* targets, size_t n,
     rc = run_exact(specs.data(), specs.size(), sc, true, po.data(), &arena);
     if (rc) return rc;
   }
+  tm.lap("run_exact");
   parallel_ranges(specs.size(), arena.size() * 4, [&](size_t lo, size_t hi) {
     for (size_t k = lo; k < hi; k++) {
       const size_t i = idx[k];
@@ -652,6 +693,7 @@ int align_many(const char* const* queries, const char* const* targets, size_t n,
       out[i] = b ? &b->r : nullptr;
     }
   });
+  tm.lap("strings");
   return SW_OK;
 }
 
