@@ -20,6 +20,11 @@
 // [2*(15 - k%16), +2); lane's row i = strip*256 + lane*RPL + r, its column at step k is j = k - lane + 1.
 #include "sw_internal.h"
 
+// back-off of the boundary poll (units of 64 clocks)
+#ifndef SW_EXACT_SLEEP
+#define SW_EXACT_SLEEP 4
+#endif
+
 namespace swhip {
 
 namespace {
@@ -184,7 +189,7 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
         __hip_atomic_store(W.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
-      __builtin_amdgcn_s_sleep(4);
+      __builtin_amdgcn_s_sleep(SW_EXACT_SLEEP);
       bnext = fetch_bnd(g);
     }
     const int bcur = (int)((uint32_t)bnext & ~kTag), tblk = tnext;
