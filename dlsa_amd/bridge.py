@@ -138,6 +138,9 @@ def lib():
     L.sw_hip_benchmark_cups.restype = C.c_float
     L.sw_hip_path_params.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
     L.sw_hip_path_params.restype = C.c_int
+    L.sw_hip_test_units.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.POINTER(C.c_uint32)]
+    L.sw_hip_test_units.restype = C.c_int64
     # include/sw_worker.h
     L.sw_execute_work.argtypes = [C.POINTER(CWorkPackage), C.POINTER(CAlignmentDetail)]
     L.sw_execute_work.restype = C.c_int

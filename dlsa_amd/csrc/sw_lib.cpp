@@ -1154,6 +1154,71 @@ void build_units(const sw_db* db, uint32_t W, uint32_t S, uint32_t R, uint32_t m
   }
 }
 
+}  // namespace
+// Test hook (host arithmetic only, no GPU): builds the ticket-ordered unit table for a database whose groups have
+// the given numbers of strips and checks the invariants the score kernel relies on -- every strip is covered
+// exactly once, units are 1..W strips, a unit that continues a group depends on the EARLIER ticket that ends right
+// before it, the ring slot it writes was last read by an earlier ticket.  Returns the number of units, or a
+// negative number naming the violated invariant.  out[0] = units of the short (tail) kind, out[1] = their size.
+extern "C" int64_t sw_hip_test_units(const uint32_t* group_strips, uint32_t n_groups, uint32_t W, uint32_t S, uint32_t R,
+                                     uint32_t max_wg, uint32_t* out) {
+  if (!group_strips || !W || !S || !R) return -100;
+  sw_db db;
+  uint32_t total = 0;
+  std::vector<uint32_t> elem_group;
+  for (uint32_t g = 0; g < n_groups; g++) {
+    ScoreGroup G{};
+    G.strip_base = total;
+    G.nstrips = group_strips[g];
+    G.first_slot = g * kGroupTargets;
+    db.groups.push_back(G);
+    for (uint32_t k = 0; k < group_strips[g]; k++) elem_group.push_back(g);
+    total += group_strips[g];
+  }
+  db.n_elems = total;
+  std::vector<ScoreUnit> units;
+  build_units(&db, W, S, R, max_wg, units);
+  std::vector<uint8_t> covered(total, 0);
+  std::vector<uint32_t> last_reader(R, UINT32_MAX);
+  uint32_t n_short = 0, short_size = 0;
+  for (uint32_t t = 0; t < units.size(); t++) {
+    const ScoreUnit& u = units[t];
+    if (u.count < 1 || u.count > W) return -1;
+    if ((uint64_t)u.first_elem + u.count > total) return -2;
+    for (uint32_t k = 0; k < u.count; k++) {
+      if (covered[u.first_elem + k]) return -3;
+      covered[u.first_elem + k] = 1;
+    }
+    const uint32_t g0 = elem_group[u.first_elem];
+    const bool continues = u.first_elem > db.groups[g0].strip_base;  // wave 0 needs a left column from another unit
+    if (continues) {
+      if (u.dep == UINT32_MAX || u.dep >= t) return -4;
+      const ScoreUnit& d = units[u.dep];
+      if (d.first_elem + d.count != u.first_elem) return -5;
+    }
+    if (u.reuse != UINT32_MAX && u.reuse >= t) return -6;
+    if (u.reuse != last_reader[t % R]) return -7;
+    if (u.dep != UINT32_MAX) {
+      if (u.dep >= t) return -8;
+      last_reader[u.dep % R] = t;
+    }
+    if (u.count < W && u.first_elem + u.count < total &&
+        elem_group[u.first_elem + u.count] == elem_group[u.first_elem + u.count - 1]) {  // short, and the group goes on
+      n_short++;
+      short_size = std::max(short_size, u.count);
+    }
+  }
+  for (uint32_t e = 0; e < total; e++)
+    if (!covered[e]) return -9;
+  if (out) {
+    out[0] = n_short;
+    out[1] = short_size;
+  }
+  return (int64_t)units.size();
+}
+
+namespace {
+
 struct QueryPrep {
   Decoded d;
   bool acgt = true;

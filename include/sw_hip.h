@@ -123,6 +123,12 @@ float sw_hip_benchmark_cups(void);
  * suite check the library's dispatch (rust/src/algorithm/mod.rs:213 and the padded-length quirks) against
  * the oracle's clean model without a GPU. */
 int sw_hip_path_params(int path, uint64_t q_len, uint64_t t_len, uint32_t out[4]);
+/* Builds the score kernel's ticket-ordered unit table for a database whose groups have the given numbers of strips
+ * (W strips per unit, S interleaved lanes, R ring slots, max_wg persistent workgroups) and checks the invariants
+ * the kernel relies on (coverage, backward dependencies, ring-slot reuse).  Returns the number of units or a
+ * negative code; out[0] = short units that cut the partial last round, out[1] = their size.  Host arithmetic. */
+int64_t sw_hip_test_units(const uint32_t *group_strips, uint32_t n_groups, uint32_t W, uint32_t S, uint32_t R,
+                          uint32_t max_wg, uint32_t out[2]);
 
 #ifdef __cplusplus
 }

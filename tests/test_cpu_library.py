@@ -108,3 +108,35 @@ def test_shard_ranges_cover_the_database():
             for (f0, c0), (f1, _) in zip(spans, spans[1:]):
                 assert f0 + c0 == f1
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+def test_score_unit_tables_keep_their_invariants(L):
+    """The ticket-ordered unit table of the score kernel (host arithmetic, sw_hip_test_units): every strip exactly
+    once, dependencies and ring-slot reuse point to EARLIER tickets (that is what makes the cross-workgroup chain
+    deadlock-free), and the partial last round is cut into short units."""
+    import random
+    rng = random.Random(9)
+
+    def run(groups, W, S, R, max_wg):
+        arr = (C.c_uint32 * len(groups))(*groups)
+        out = (C.c_uint32 * 2)()
+        n = L.sw_hip_test_units(arr, len(groups), W, S, R, max_wg, out)
+        assert n > 0, (n, len(groups), W, S, R, max_wg)
+        return n, out[0], out[1]
+
+    # the bench shape: 782 groups of 63 strips, 16-wave workgroups on 256 CUs
+    n, n_short, short = run([63] * 782, 16, 16, 16 + 256 * 2 + 8, 256)
+    assert n >= (782 * 63 + 15) // 16 and n_short > 0 and short <= 4
+    # a multiple of the machine: nothing to cut (12 rounds exactly is not reachable with 63-strip groups, use 64)
+    n, n_short, _ = run([64] * 768, 16, 16, 600, 256)
+    assert n == 768 * 4 and n_short == 0
+    # small databases (4-wave workgroups), skewed lengths, single-strip groups, random geometry
+    run([63] * 8, 4, 8, 8 + 768 + 8, 768)
+    run([1] * 1000, 16, 8, 300, 256)
+    run([rng.randint(13, 313) for _ in range(7813)], 16, 64, 64 + 256 * 9 + 8, 256)
+    for _ in range(60):
+        groups = [rng.randint(1, rng.choice([3, 40, 400])) for _ in range(rng.randint(1, 300))]
+        W = rng.choice([4, 8, 16])
+        max_wg = rng.choice([3, 64, 256, 512, 768])
+        S = rng.randint(1, 70)
+        run(groups, W, S, S + max_wg * rng.randint(2, 9) + 8, max_wg)
