@@ -6,9 +6,9 @@
 // algorithm/mod.rs:665-706.  It is not a translation: the reference fills a skewed i16 matrix row by
 // row; here a 64-lane wavefront sweeps a strip of 256 query rows (4 per lane) along the target as an
 // anti-diagonal wavefront and passes H across lanes with a DPP wave shift; every strip of a pair has its own
-// wave and the strips pipeline along the target across the whole GPU (strip boundary rows and progress words
-// in HBM at device scope, tickets in (pair, strip) order); only 2 direction bits per cell are kept for the
-// traceback walker.
+// wave and the strips pipeline along the target across the whole GPU (strip boundary rows in HBM at device
+// scope, each word carrying its own "published" tag in bit 31 so no separate progress flag is polled; tickets
+// in (pair, strip) order); only 2 direction bits per cell are kept for the traceback walker.
 //
 // Arithmetic: int32 (the "int32 re-run" of the north star; equal to the reference's wrapping i16 on its
 // safe domain max H <= 32767).
