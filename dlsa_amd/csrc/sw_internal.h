@@ -6,6 +6,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <exception>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -13,6 +15,28 @@ namespace swhip {
 
 // records the calling thread's last error message (sw_hip_last_error)
 void set_last_error(const std::string& msg);
+
+// No C++ exception may cross the C ABI: the reference turns every internal failure into NULL
+// (rust/src/bindings.rs:109-112, 153-156) and a cgo caller cannot unwind.  Every extern "C" entry point that
+// can allocate runs its body through this; `on_error` is what the caller sees, the message goes to
+// sw_hip_last_error().
+template <class R, class F>
+R guarded(R on_error, F&& body) noexcept {
+  const char* what = "internal error";
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    what = "out of host memory";
+  } catch (const std::exception&) {
+    what = "internal error (C++ exception)";
+  } catch (...) {
+  }
+  try {
+    set_last_error(what);
+  } catch (...) {
+  }
+  return on_error;
+}
 
 // ---- scoring ------------------------------------------------------------------------------------------
 struct Scoring {

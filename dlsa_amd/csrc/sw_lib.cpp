@@ -615,13 +615,31 @@ template <class F>
 void parallel_ranges(size_t n, size_t work, F&& f) {
   unsigned nt = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
   if (work < (1u << 20) || n < 2 * nt) nt = 1;
+  // an exception inside a helper thread would end the process: it is caught there and re-raised by the caller
+  std::atomic<bool> failed{false};
+  auto run = [&](size_t lo, size_t hi) noexcept {
+    try {
+      f(lo, hi);
+    } catch (...) {
+      failed.store(true);
+    }
+  };
   std::vector<std::thread> th;
+  th.reserve(nt);
   for (unsigned t = 0; t < nt; t++) {
     const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
-    if (t + 1 == nt) f(lo, hi);
-    else th.emplace_back([=, &f] { f(lo, hi); });
+    if (t + 1 == nt) {
+      run(lo, hi);
+    } else {
+      try {
+        th.emplace_back(run, lo, hi);
+      } catch (...) {  // no thread to be had: do the range here
+        run(lo, hi);
+      }
+    }
   }
   for (auto& x : th) x.join();
+  if (failed.load()) throw std::bad_alloc();
 }
 
 int align_many(const char* const* queries, const char* const* targets, size_t n, AlignmentScores as, int path,
@@ -738,7 +756,9 @@ void combine_run_batch(std::vector<OneReq*>& batch) {
       ts[k] = batch[grp[k]]->t;
     }
     g_err.clear();
-    const int rc = align_many(qs.data(), ts.data(), grp.size(), batch[i]->as, batch[i]->path, out.data());
+    const int rc = swhip::guarded<int>(SW_E_NOMEM, [&] {
+      return align_many(qs.data(), ts.data(), grp.size(), batch[i]->as, batch[i]->path, out.data());
+    });
     for (size_t k = 0; k < grp.size(); k++) {
       OneReq* r = batch[grp[k]];
       r->rc = rc;
@@ -775,7 +795,12 @@ Result* align_one(char* query, char* target, AlignmentScores as, int path) {
       batch.swap(g_comb_pending);
       g_comb_expect = std::max(batch.size(), g_comb_expect - (g_comb_expect + 3) / 4);
       lk.unlock();
-      combine_run_batch(batch);
+      try {
+        combine_run_batch(batch);
+      } catch (...) {  // out of host memory while grouping: the batch fails, the protocol goes on
+        for (OneReq* r : batch)
+          if (!r->out) r->rc = SW_E_NOMEM;
+      }
       lk.lock();
       for (OneReq* r : batch) r->done = true;
       g_comb_cv.notify_all();
@@ -784,8 +809,12 @@ Result* align_one(char* query, char* target, AlignmentScores as, int path) {
     g_comb_cv.notify_all();  // a waiter whose request is still queued takes over
   }
   lk.unlock();
-  if (!me.out) g_err = me.err;
+  if (!me.out) g_err = me.err.empty() && me.rc == SW_E_NOMEM ? std::string("out of host memory") : me.err;
   return me.out;
+}
+// the three drop-in entry points: any failure, a C++ exception included, is a NULL result
+Result* align_one_guarded(char* query, char* target, AlignmentScores as, int path) {
+  return swhip::guarded<Result*>(nullptr, [&] { return align_one(query, target, as, path); });
 }
 
 }  // namespace
@@ -796,13 +825,13 @@ Result* align_one(char* query, char* target, AlignmentScores as, int path) {
 extern "C" {
 
 Result* find_alignment_low_memory(char* query, char* target, AlignmentScores s) {
-  return align_one(query, target, s, SW_PATH_LOW_MEMORY);
+  return align_one_guarded(query, target, s, SW_PATH_LOW_MEMORY);
 }
 Result* find_alignment_simd(char* query, char* target, AlignmentScores s) {
-  return align_one(query, target, s, SW_PATH_SIMD);
+  return align_one_guarded(query, target, s, SW_PATH_SIMD);
 }
 Result* find_alignment_sequential_straight(char* query, char* target, AlignmentScores s) {
-  return align_one(query, target, s, SW_PATH_STRAIGHT);
+  return align_one_guarded(query, target, s, SW_PATH_STRAIGHT);
 }
 Result* find_alignment_parallel(char*, char*, size_t, AlignmentScores) {
   g_err = "find_alignment_parallel is declared by rust/header/sw.h but not defined by the reference";
@@ -841,8 +870,10 @@ void free_c_string(char* str) {
 // include/sw_hip.h
 // ================================================================================================
 int sw_hip_init(int device) {
-  std::lock_guard<std::mutex> lk(g_ctx.mu);
-  return ctx_init_locked(device);
+  return swhip::guarded<int>(SW_E_NOMEM, [&] {
+    std::lock_guard<std::mutex> lk(g_ctx.mu);
+    return ctx_init_locked(device);
+  });
 }
 const char* sw_hip_last_error(void) { return g_err.c_str(); }
 const char* sw_hip_version(void) { return "libsw_hip 0.1 (gfx950; exact int32 wavefront + packed-int16 inter-task kernels)"; }
@@ -855,7 +886,15 @@ int32_t sw_result_score32(const Result* result) {
 
 int sw_align_batch(const char* const* queries, const char* const* targets, size_t n_pairs, AlignmentScores scores,
                    int path, Result** out) {
-  return align_many(queries, targets, n_pairs, scores, path, out);
+  if (out)
+    for (size_t i = 0; i < n_pairs; i++) out[i] = nullptr;
+  const int rc = swhip::guarded<int>(SW_E_NOMEM, [&] { return align_many(queries, targets, n_pairs, scores, path, out); });
+  if (rc != SW_OK && out)  // nothing is handed over on failure
+    for (size_t i = 0; i < n_pairs; i++) {
+      free_alignment_result(out[i]);
+      out[i] = nullptr;
+    }
+  return rc;
 }
 
 int sw_hip_path_params(int path, uint64_t q_len, uint64_t t_len, uint32_t out[4]) {
@@ -1163,6 +1202,7 @@ void build_units(const sw_db* db, uint32_t W, uint32_t S, uint32_t R, uint32_t m
 extern "C" int64_t sw_hip_test_units(const uint32_t* group_strips, uint32_t n_groups, uint32_t W, uint32_t S, uint32_t R,
                                      uint32_t max_wg, uint32_t* out) {
   if (!group_strips || !W || !S || !R) return -100;
+  return swhip::guarded<int64_t>(-101, [&]() -> int64_t {
   sw_db db;
   uint32_t total = 0;
   std::vector<uint32_t> elem_group;
@@ -1215,6 +1255,7 @@ extern "C" int64_t sw_hip_test_units(const uint32_t* group_strips, uint32_t n_gr
     out[1] = short_size;
   }
   return (int64_t)units.size();
+  });
 }
 
 namespace {
@@ -1501,6 +1542,7 @@ bool prep_query(const char* query, QueryPrep& qp) {
 extern "C" {
 
 sw_db* sw_db_create(const char* flat, const uint64_t* offsets, uint64_t n) {
+  return swhip::guarded<sw_db*>(nullptr, [&]() -> sw_db* {
   if ((!flat && n) || !offsets) {
     fail(SW_E_ARG, "null argument");
     return nullptr;
@@ -1516,6 +1558,7 @@ sw_db* sw_db_create(const char* flat, const uint64_t* offsets, uint64_t n) {
   for (uint64_t i = 0; i <= n; i++) off[i] = offsets[i] - offsets[0];
   std::string f(flat + offsets[0], flat + offsets[n]);
   return db_build(std::move(f), std::move(off));
+  });
 }
 
 sw_db* sw_db_load_fasta(const char* path) {
@@ -1540,6 +1583,7 @@ uint64_t sw_db_size(const sw_db* db) { return db ? db->n : 0; }
 uint64_t sw_db_residues(const sw_db* db) { return db ? db->residues : 0; }
 
 int sw_db_scores(sw_db* db, const char* query, AlignmentScores as, int32_t* scores_out) {
+  return swhip::guarded<int>(SW_E_NOMEM, [&]() -> int {
   if (!db || !query || !scores_out) return fail(SW_E_ARG, "null argument");
   QueryPrep qp;
   if (!prep_query(query, qp)) return fail(SW_E_ARG, "query is not valid UTF-8");
@@ -1553,10 +1597,11 @@ int sw_db_scores(sw_db* db, const char* query, AlignmentScores as, int32_t* scor
   if (rc) return rc;
   memcpy(scores_out, scores.data(), scores.size() * sizeof(int32_t));
   return SW_OK;
+  });
 }
 
-int sw_db_search_topk_batch(sw_db* db, const char* const* queries, size_t n_queries, AlignmentScores as, int k,
-                            sw_hit* hits, int* n_hits) {
+static int db_search_topk_batch(sw_db* db, const char* const* queries, size_t n_queries, AlignmentScores as, int k,
+                                sw_hit* hits, int* n_hits) {
   if (!db || (!queries && n_queries) || !hits || !n_hits || k < 0) return fail(SW_E_ARG, "bad argument");
   for (size_t q = 0; q < n_queries; q++) n_hits[q] = 0;
   if (n_queries == 0 || k == 0) return SW_OK;
@@ -1629,6 +1674,17 @@ int sw_db_search_topk_batch(sw_db* db, const char* const* queries, size_t n_quer
   return SW_OK;
 }
 
+int sw_db_search_topk_batch(sw_db* db, const char* const* queries, size_t n_queries, AlignmentScores as, int k,
+                            sw_hit* hits, int* n_hits) {
+  const int rc = swhip::guarded<int>(SW_E_NOMEM, [&] { return db_search_topk_batch(db, queries, n_queries, as, k, hits, n_hits); });
+  if (rc == SW_E_NOMEM && hits && n_hits && k > 0)  // an exception may have left some hits filled: hand over nothing
+    for (size_t q = 0; q < n_queries; q++) {
+      sw_hits_free(hits + q * (size_t)k, n_hits[q]);
+      n_hits[q] = 0;
+    }
+  return rc;
+}
+
 int sw_db_search_topk(sw_db* db, const char* query, AlignmentScores as, int k, sw_hit* hits, int* n_hits) {
   if (!query) return fail(SW_E_ARG, "bad argument");
   return sw_db_search_topk_batch(db, &query, 1, as, k, hits, n_hits);
@@ -1644,6 +1700,7 @@ void sw_hits_free(sw_hit* hits, int n_hits) {
 }
 
 float sw_hip_benchmark_cups(void) {
+  return swhip::guarded<float>(0.0f, [&]() -> float {
   // internal/worker/worker_rust_benchmark.go:38-68 measures one CPU thread on one synthetic pair; a GPU
   // worker runs work packages through the batch path, so that is what is timed here: 1 query (4096 nt) x
   // 16384 targets (1024 nt) of seeded uniform DNA, match 1 / mismatch -1 / gap -2 (the reference's
@@ -1681,6 +1738,7 @@ float sw_hip_benchmark_cups(void) {
   }
   sw_db_free(db);
   return (float)(double)(uint64_t)best;
+  });
 }
 
 }  // extern "C"

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -47,7 +48,7 @@ bool fill_detail(sw_alignment_detail& d, Result* r, int entry) {
 
 extern "C" {
 
-int sw_execute_work(const sw_work_package* work, sw_alignment_detail* out) {
+static int execute_work(const sw_work_package* work, sw_alignment_detail* out, bool& out_initialised) {
   if (!work || (work->n_pairs && (!work->pairs || !out)) || (work->n_sequences && !work->sequences)) {
     set_last_error("sw_execute_work: null argument");
     return SW_E_ARG;
@@ -66,6 +67,7 @@ int sw_execute_work(const sw_work_package* work, sw_alignment_detail* out) {
     out[i].entry = -1;
   }
   // worker_impl.go:126-127: {MatchScore, -MismatchPenalty, -GapPenalty}; worker_rust_bridge.go:108-112: C.ushort(...)
+  out_initialised = true;
   AlignmentScores sc;
   sc.match = (uint16_t)work->match_score;
   sc.miss = (uint16_t)(-work->mismatch_penalty);
@@ -110,6 +112,17 @@ int sw_execute_work(const sw_work_package* work, sw_alignment_detail* out) {
   return SW_OK;
 }
 
+int sw_execute_work(const sw_work_package* work, sw_alignment_detail* out) {
+  bool out_initialised = false, returned = false;
+  const int rc = swhip::guarded<int>(SW_E_NOMEM, [&] {
+    const int r = execute_work(work, out, out_initialised);
+    returned = true;
+    return r;
+  });
+  if (!returned && out_initialised) sw_alignment_details_free(out, work->n_pairs);  // left by an exception
+  return rc;
+}
+
 void sw_alignment_details_free(sw_alignment_detail* d, uint64_t n) {
   if (!d) return;
   for (uint64_t i = 0; i < n; i++) {
@@ -144,6 +157,7 @@ bool run_once(size_t nQ, size_t nT, double& elapsed_s, float& cups) {
 }  // namespace
 
 float sw_benchmark_rust(double threshold_seconds, int q_steps, int t_steps) {
+  return swhip::guarded<float>(0.0f, [&]() -> float {
   if (q_steps < 1 || t_steps < 1 || q_steps + t_steps > 20) {
     set_last_error("sw_benchmark_rust: bad step counts");
     return 0.0f;
@@ -167,6 +181,7 @@ float sw_benchmark_rust(double threshold_seconds, int q_steps, int t_steps) {
       sum += cups;
     }
   return sum / (float)(q_steps * t_steps);
+  });
 }
 
 }  // extern "C"
@@ -184,6 +199,7 @@ inline bool py_space(unsigned char c) { return c == ' ' || (c >= 9 && c <= 13) |
 extern "C" {
 
 sw_fasta* sw_fasta_parse(const char* path) {
+  return swhip::guarded<sw_fasta*>(nullptr, [&]() -> sw_fasta* {
   if (!path) {
     set_last_error("sw_fasta_parse: null path");
     return nullptr;
@@ -194,10 +210,19 @@ sw_fasta* sw_fasta_parse(const char* path) {
     return nullptr;
   }
   std::string raw;
-  char buf[1 << 16];
-  size_t got;
-  while ((got = fread(buf, 1, sizeof buf, fp)) > 0) raw.append(buf, got);
-  fclose(fp);
+  {
+    struct Closer {
+      FILE* f;
+      ~Closer() { fclose(f); }
+    } closer{fp};
+    std::vector<char> buf(1 << 16);
+    size_t got;
+    while ((got = fread(buf.data(), 1, buf.size(), fp)) > 0) raw.append(buf.data(), got);
+    if (ferror(fp)) {
+      set_last_error(std::string("sw_fasta_parse: read error on ") + path);
+      return nullptr;
+    }
+  }
   // open(..., "r"): universal newlines -- "\r\n" and lone "\r" become "\n"
   std::string data;
   data.reserve(raw.size());
@@ -209,7 +234,7 @@ sw_fasta* sw_fasta_parse(const char* path) {
       data.push_back(raw[i]);
     }
   }
-  sw_fasta* f = new sw_fasta;
+  std::unique_ptr<sw_fasta> f(new sw_fasta);
   // fasta_data.split(">")[1:]
   size_t pos = data.find('>');
   while (pos != std::string::npos) {
@@ -226,7 +251,6 @@ sw_fasta* sw_fasta_parse(const char* path) {
     while (ie < eol && !py_space((unsigned char)data[ie])) ie++;
     if (ie == ib) {  // lines[0].split() is empty: IndexError in the reference
       set_last_error("sw_fasta_parse: record without an id in " + std::string(path));
-      delete f;
       return nullptr;
     }
     std::string seq;
@@ -234,14 +258,14 @@ sw_fasta* sw_fasta_parse(const char* path) {
       if (data[i] != '\n') seq.push_back(data[i]);
     if (seq.find('\0') != std::string::npos) {
       set_last_error("sw_fasta_parse: NUL byte inside a sequence");
-      delete f;
       return nullptr;
     }
     f->ids.emplace_back(data, ib, ie - ib);
     f->seqs.push_back(std::move(seq));
     pos = next;
   }
-  return f;
+  return f.release();
+  });
 }
 
 uint64_t sw_fasta_count(const sw_fasta* f) { return f ? f->ids.size() : 0; }
@@ -252,6 +276,7 @@ const char* sw_fasta_sequence(const sw_fasta* f, uint64_t i) {
 void sw_fasta_free(sw_fasta* f) { delete f; }
 
 sw_db* sw_db_from_fasta(const sw_fasta* f) {
+  return swhip::guarded<sw_db*>(nullptr, [&]() -> sw_db* {
   if (!f) {
     set_last_error("sw_db_from_fasta: null argument");
     return nullptr;
@@ -263,10 +288,12 @@ sw_db* sw_db_from_fasta(const sw_fasta* f) {
     off[i + 1] = flat.size();
   }
   return sw_db_create(flat.data(), off.data(), f->seqs.size());
+  });
 }
 
 int sw_write_query_results(const char* results_dir, const char* query_id, const char* const* target_ids,
                            const sw_hit* hits, int n_hits) {
+  return swhip::guarded<int>(SW_E_NOMEM, [&]() -> int {
   if (!results_dir || !query_id || n_hits < 0 || (n_hits && (!target_ids || !hits))) {
     set_last_error("sw_write_query_results: bad argument");
     return SW_E_ARG;
@@ -292,8 +319,13 @@ int sw_write_query_results(const char* results_dir, const char* query_id, const 
   for (int i = 0; i < n_hits; i++)
     fprintf(fp, ">%s\nAlignment: %s\nLength: %u\nScore: %d\n\n", target_ids[i] ? target_ids[i] : "",
             hits[i].query_aln ? hits[i].query_aln : "", hits[i].length, hits[i].score);
-  fclose(fp);
+  const bool bad = ferror(fp) != 0;
+  if (fclose(fp) != 0 || bad) {
+    set_last_error("sw_write_query_results: write error on " + path + ": " + strerror(errno));
+    return SW_E_ARG;
+  }
   return SW_OK;
+  });
 }
 
 }  // extern "C"

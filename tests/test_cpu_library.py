@@ -140,3 +140,26 @@ def test_score_unit_tables_keep_their_invariants(L):
         max_wg = rng.choice([3, 64, 256, 512, 768])
         S = rng.randint(1, 70)
         run(groups, W, S, S + max_wg * rng.randint(2, 9) + 8, max_wg)
+
+
+def test_no_exception_crosses_the_c_abi(L):
+    """The reference turns every internal failure into NULL / an error code (rust/src/bindings.rs:109-112) and a cgo
+    caller cannot unwind a C++ exception: an allocation failure inside an entry point must come back as an error
+    code with a message.  Provoked in a child process under an address-space limit (host arithmetic only, no GPU)."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, resource
+L = ctypes.CDLL(%r)
+L.sw_hip_test_units.restype = ctypes.c_int64
+L.sw_hip_test_units.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_uint32] + [ctypes.c_uint32] * 4 + [ctypes.POINTER(ctypes.c_uint32)]
+L.sw_hip_last_error.restype = ctypes.c_char_p
+resource.setrlimit(resource.RLIMIT_AS, (3 << 30, 3 << 30))
+g = (ctypes.c_uint32 * 4)(*[1 << 30] * 4)
+out = (ctypes.c_uint32 * 2)()
+rc = L.sw_hip_test_units(g, 4, 16, 16, 64, 256, out)
+print(rc, L.sw_hip_last_error().decode())
+''' % os.path.join(ROOT, "dlsa_amd", "lib", "libsw_hip.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split()[0] == "-101" and "out of host memory" in r.stdout, r.stdout
