@@ -127,7 +127,7 @@ def generate():
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     # ring geometry must match sw_score.hip: D slots x B rows x 256 bytes per wave
-    Dslots, B = 2, 16
+    Dslots, B = 3, 12  # defaults of sw_score.hip (the asm text itself does not depend on them; B must be even)
     lines = generate()
     if NO_NOPS:
         lines = [ln for ln in lines if ln != "s_nop 0"]

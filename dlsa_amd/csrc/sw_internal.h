@@ -107,7 +107,10 @@ hipError_t launch_walk(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pa
 
 // ---- inter-task score kernel ---------------------------------------------------------------------------
 constexpr int kScoreR = 16;       // target columns per wave (one 2-bit packed dword per target)
-constexpr int kScoreB = 16;       // query rows per hand-over block (one 2-bit packed dword of the query)
+#ifndef SW_SCORE_B
+#define SW_SCORE_B 12
+#endif
+constexpr int kScoreB = SW_SCORE_B;       // query rows per hand-over block (one 2-bit packed dword of the query)
 constexpr int kGroupTargets = 128; // 64 lanes x 2 packed int16 halves
 
 // The packed database is one stream of STRIPS: all strips of group 0, then group 1, ...; strip e occupies

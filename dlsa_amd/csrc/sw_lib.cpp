@@ -1281,9 +1281,10 @@ int score_pass_locked(sw_db* db, const QueryPrep& qp, Scoring sc) {
   const uint32_t max_wg = (uint32_t)c.cus * (uint32_t)score_workgroups_per_cu((int)W);
   // interleave: a unit should be handed out about 40 blocks after the unit it continues, i.e. when that
   // one's last wave is publishing; max_wg workgroups draw max_wg tickets per (nblk + drain) blocks
-  const uint32_t S = std::min<uint32_t>(1024, std::max<uint32_t>(8, max_wg * 40 / (nblk + 16)));
+  const uint32_t nblk16 = (Q + 15) / 16;
+  const uint32_t S = std::min<uint32_t>(1024, std::max<uint32_t>(8, max_wg * 40 / (nblk16 + 16)));
   // boundary ring: a workgroup has at most 1 + queue depth units in flight, fewer when a unit is long
-  const uint32_t ahead = std::min<uint32_t>(score_queue_depth(), 48 / nblk + 1);
+  const uint32_t ahead = std::min<uint32_t>(score_queue_depth(), 48 / nblk16 + 1);
   const uint32_t ring_slots = S + max_wg * (1 + ahead) + 8;
   if (db->units_S != S || db->units_R != ring_slots || db->units_W != W || !db->d_units) {
     std::vector<ScoreUnit> units;
@@ -1330,7 +1331,9 @@ int score_pass_locked(sw_db* db, const QueryPrep& qp, Scoring sc) {
   p.miss = sc.miss;
   p.gap = sc.gap;
   // a small database is a few chains of units: publish their boundary columns often (latency), a big one rarely
-  p.pub = W == 4 ? 2 : 8;
+  // (in blocks; swept: 10 kb queries like 10 blocks, 1 kb queries 5 -- a short unit is over before a coarse
+  // publication lets its consumer start)
+  p.pub = W == 4 ? 2 : nblk >= 400 ? 10 : 5;
   if (const char* e = getenv("SW_HIP_SCORE_PUB")) p.pub = std::max(1, atoi(e));  // experiments
   HIPCK(hipEventRecord(c.ev0, c.stream));
   HIPCK(launch_score(p, nwg, (int)W, c.stream));
@@ -1525,14 +1528,14 @@ int db_topk_locked(sw_db* db, const QueryPrep& qp, Scoring sc, size_t k, std::ve
 bool prep_query(const char* query, QueryPrep& qp) {
   if (!decode(query, qp.d)) return false;
   const size_t Q = qp.d.sym.size();
-  qp.qwords.assign((Q + 15) / 16 + 1, 0);
+  qp.qwords.assign((Q + kScoreB - 1) / kScoreB + 1, 0);  // one word per block of rows, 2 bits per row
   for (size_t i = 0; i < Q; i++) {
     int code = qp.d.cp(i) < 128 ? nt_code((unsigned char)qp.d.cp(i)) : -1;
     if (code < 0) {
       qp.acgt = false;
       code = 0;
     }
-    qp.qwords[i / 16] |= (uint32_t)code << (2 * (i % 16));
+    qp.qwords[i / kScoreB] |= (uint32_t)code << (2 * (i % kScoreB));
   }
   return true;
 }
