@@ -1279,12 +1279,20 @@ int score_pass_locked(sw_db* db, const QueryPrep& qp, Scoring sc) {
   const size_t Qpad = (size_t)nblk * kScoreB;
   const uint32_t W = (uint32_t)score_waves_per_group(db->n_elems, c.cus);
   const uint32_t max_wg = (uint32_t)c.cus * (uint32_t)score_workgroups_per_cu((int)W);
-  // interleave: a unit should be handed out about 40 blocks after the unit it continues, i.e. when that
-  // one's last wave is publishing; max_wg workgroups draw max_wg tickets per (nblk + drain) blocks
+  // Active lanes S of the ticket order (build_units): the unit that continues a group is handed out S tickets
+  // after its producer.  With S beyond the number of resident workgroups the producer has FINISHED by then and the
+  // consumer never waits; a consumer that trails a running producer (small S) costs 5-9 % whatever the lag
+  // (swept 1..8192 on every shape of scratch/sweep.py: flat from ~512 up).  So: as many lanes as the database has
+  // groups, up to 1024, as long as the boundary ring (one slot of Qpad x 256 B per unit in flight or waiting) stays
+  // within twice the scratch budget; a database with few groups or a very long query falls back to chains.
   const uint32_t nblk16 = (Q + 15) / 16;
-  const uint32_t S = std::min<uint32_t>(1024, std::max<uint32_t>(8, max_wg * 40 / (nblk16 + 16)));
   // boundary ring: a workgroup has at most 1 + queue depth units in flight, fewer when a unit is long
   const uint32_t ahead = std::min<uint32_t>(score_queue_depth(), 48 / nblk16 + 1);
+  const uint32_t ring_min = max_wg * (1 + ahead) + 8;
+  const uint64_t ring_fit = 2 * (uint64_t)c.scratch_budget / ((uint64_t)Qpad * 256);
+  uint32_t S = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(8, db->groups.size()));
+  if (ring_fit < (uint64_t)ring_min + S) S = (uint32_t)std::max<uint64_t>(8, ring_fit > ring_min ? ring_fit - ring_min : 0);
+  if (const char* e = getenv("SW_HIP_SCORE_LANES")) S = std::min(16384, std::max(1, atoi(e)));  // experiments
   const uint32_t ring_slots = S + max_wg * (1 + ahead) + 8;
   if (db->units_S != S || db->units_R != ring_slots || db->units_W != W || !db->d_units) {
     std::vector<ScoreUnit> units;

@@ -80,6 +80,10 @@ if "c2" in which: db_case("C2 10kb x 100000x1kb", 10000, np.full(100000, 1000))
 if "c2x4" in which: db_case("C2x4 10kb x 400000x1kb", 10000, np.full(400000, 1000))
 if "c2q" in which: db_case("C2q 2.5kb x 400000x1kb", 2500, np.full(400000, 1000))
 if "c2t" in which: db_case("C2t 10kb x 25000x4kb", 10000, np.full(25000, 4000))
+for w in which:
+    if w.startswith("gen:"):  # gen:Q:N:T  -- one query of Q nt against N targets of T nt
+        _, gq, gn, gt = w.split(":")
+        db_case(w, int(gq), np.full(int(gn), int(gt)))
 if "c3" in which: db_case("C3 (1 of 32 queries) 1kb x 1e6xU[200,5000]", 1000, rng.integers(200, 5001, size=1000000))
 if "c5" in which: db_case("C5 (1 of 1000 queries) 150 x 1e7x150", 150, np.full(10000000, 150))
 if "c5s" in which: db_case("C5 scaled 150 x 1e6x150", 150, np.full(1000000, 150))
