@@ -39,10 +39,10 @@ OPS_PER_CELL = 6                            # algorithmic i16 ops 
 PEAK_TOPS = 78.6                            # 256 CU x 64 lanes/clk x 2 (packed) x 2.4 GHz, BASELINE.md 3
 SEED = 0xD15A
 # HBM-side bytes of one score-kernel launch on the default workload, from the PMC passes committed under
-# profiles/ (r01_pmc_summary.csv: WRITE_SIZE 7.61e6 KB + 2 x FETCH_SIZE 3.86e6 KB, the gfx950 half-count
+# profiles/ (r01_pmc_summary.csv: WRITE_SIZE 6.32e6 KB + 2 x FETCH_SIZE 3.16e6 KB, the gfx950 half-count
 # corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes); counters cannot be read from inside
 # this process, so the figure is only attached when the shape is the profiled one.
-TRAFFIC_DEFAULT_BYTES = 7.6073e9 + 2 * 3.8634e9
+TRAFFIC_DEFAULT_BYTES = 6.3164e9 + 2 * 3.1593e9
 
 
 def synth(rng, n, length):

@@ -117,8 +117,8 @@ constexpr int kGroupTargets = 128; // 64 lanes x 2 packed int16 halves
 // dwords [e*128, e*128+128) of `words` ([half][lane], 16 residues per dword).  A work unit is W consecutive
 // strips of that stream (W = waves per workgroup), whatever groups they belong to.  The stream is cut into
 // LANES (runs of whole groups that fill their last unit well); tickets visit S lanes round-robin, so the unit
-// that continues a group is handed out S tickets after the unit it depends on, when that one is well under
-// way -- its first wave does not sit waiting for the producer's last wave to get going.
+// that continues a group is handed out S tickets after the unit it depends on -- with S beyond the number of
+// resident workgroups (the normal case, sw_lib.cpp: score_pass_locked) after that one has finished.
 struct ScoreGroup {       // one group of up to 128 length-sorted targets
   uint32_t strip_base;    // index of this group's first strip in the stream
   uint32_t nstrips;       // ceil(max length / 16)

@@ -934,7 +934,7 @@ struct sw_db {
   ScoreGroup* d_groups = nullptr;
   uint32_t* d_elem_group = nullptr;  // per strip of the stream: its group
   uint32_t n_elems = 0;              // strips in the stream
-  // ticket-ordered unit table, rebuilt when the interleave / ring geometry of a search differs (build_units)
+  // ticket-ordered unit table, rebuilt when the lane count / ring geometry of a search differs (build_units)
   ScoreUnit* d_units = nullptr;
   uint32_t n_units = 0, units_S = 0, units_R = 0, units_W = 0;
   std::vector<uint32_t> generic;  // targets scored by the exact kernel only
