@@ -74,11 +74,12 @@ __device__ __forceinline__ uint32_t push_dir_bits(uint32_t acc, int a1, int b1, 
   return acc;
 }
 
-// One 256-row strip of one pair per WAVE.  Tickets are drawn in (pair, strip) order, so the strip above mine
-// always belongs to an earlier ticket: its wave is resident or has finished, whatever the dispatch order, and
-// the chain of strips cannot deadlock.  All strips of a pair run concurrently as a pipeline along the target,
-// spread over the whole GPU; strip s trails strip s-1 by about 100 steps (64 lanes of skew + one 16-column
-// hand-over block + the prefetch distance).
+// One 256-row strip of one pair per WAVE.  Tickets are drawn strip level by level (every pair's strip 0, then
+// every strip 1, ...: W.unit_order), so the strip above mine always belongs to an earlier ticket: its wave is
+// resident or has finished, whatever the dispatch order, and the chain of strips cannot deadlock.  The strips of
+// ONE long pair run concurrently as a pipeline along the target, spread over the whole GPU; strip s trails strip
+// s-1 by about 100 steps (64 lanes of skew + one 16-column hand-over block + the prefetch distance).  In a big
+// submission the level order puts thousands of tickets between a strip and the one above: no trailing, no polls.
 //
 // 16 steps of the wavefront.  MASK = false is the interior of the matrix (every column any lane touches is
 // <= min(Tlim, T0), miss < 0 and gap < 0): cells outside the matrix (columns < 1 of lanes that have not
@@ -259,9 +260,10 @@ __global__ void __launch_bounds__(64) sw_exact_kernel(ExactWork W, int match, in
   if (lane == 0) t = atomicAdd(W.ticket, 1u);
   const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
   if (ticket >= W.n_units) return;
-  const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.unit_pair[ticket]);
+  const uint32_t rec = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.unit_order[ticket]);
+  const uint32_t p = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.unit_pair[rec]);
   const ExactPair P = W.pairs[p];
-  const uint32_t strip = ticket - P.first_unit;
+  const uint32_t strip = rec - P.first_unit;
   const uint32_t maxcol = P.Tlim > P.T0 ? P.Tlim : P.T0;
   int gbv = 0;
   uint64_t gkey = ~0ull;
@@ -274,9 +276,9 @@ __global__ void __launch_bounds__(64) sw_exact_kernel(ExactWork W, int match, in
   wave_best(gbv, gkey);
   // The last strip of a pair to finish combines the per-strip records (threadfence reduction).
   if (lane == 0) {
-    __hip_atomic_store(&W.recs[ticket].score, gbv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&W.recs[ticket].key_lo, (uint32_t)gkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&W.recs[ticket].key_hi, (uint32_t)(gkey >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&W.recs[rec].score, gbv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&W.recs[rec].key_lo, (uint32_t)gkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&W.recs[rec].key_hi, (uint32_t)(gkey >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   uint32_t prev = 0;

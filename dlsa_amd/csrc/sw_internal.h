@@ -61,7 +61,7 @@ struct ExactPair {
   uint32_t* dirs;     // nullptr: score + best cell only.  Else 2 bits per cell (layout in sw_exact.hip)
   uint32_t nkb;       // 16-step blocks per strip
   uint8_t* ops;       // traceback ops written by the walker (capacity Q + T)
-  uint32_t first_unit; // ticket of this pair's strip 0 (tickets are drawn in (pair, strip) order)
+  uint32_t first_unit; // record index of this pair's strip 0 (records are in (pair, strip) order; tickets: ExactWork::unit_order)
   uint32_t n_units;    // max(number of strips, 1)
 };
 struct ExactOut {
@@ -92,7 +92,8 @@ struct ExactRec {
 struct ExactWork {
   const ExactPair* pairs;
   ExactOut* outs;
-  const uint32_t* unit_pair;  // per ticket: index of its pair
+  const uint32_t* unit_pair;  // per record (first_unit + strip): index of its pair
+  const uint32_t* unit_order; // per ticket: the record it works on (strip level by level, sw_lib.cpp)
   uint32_t n_units;
   uint32_t n_pairs;
   int rpl;              // rows per lane of this launch: 4, 2 or 1

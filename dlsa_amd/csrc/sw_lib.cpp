@@ -295,14 +295,34 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
       e.ops = nullptr;
     }
   }
-  tm.lap("  chunk: tables");
   const size_t n_units = unit_pair.size();
+  // Ticket order: strip level by level (all pairs' strip 0, then every strip 1, ...; longest pairs first within a
+  // level), so that in a big submission the strip above has long finished when a strip starts, instead of the
+  // strips of one pair trailing each other through HBM with adjacent tickets.  The strip above always has an
+  // EARLIER ticket, which is all the kernel needs.  unit_order[ticket] = record index (first_unit + strip).
+  std::vector<uint32_t> unit_order;
+  unit_order.reserve(n_units);
+  {
+    uint32_t max_units = 0;
+    for (size_t i = 0; i < n; i++) max_units = std::max(max_units, hp[i].n_units);
+    std::vector<uint32_t> by_len(n);
+    std::iota(by_len.begin(), by_len.end(), 0u);
+    if (max_units > 1)
+      std::stable_sort(by_len.begin(), by_len.end(), [&](uint32_t a, uint32_t b) { return hp[a].n_units > hp[b].n_units; });
+    size_t live = n;  // pairs that still have a strip at this level: a prefix of by_len
+    for (uint32_t s = 0; s < max_units; s++) {
+      while (live > 0 && hp[by_len[live - 1]].n_units <= s) live--;
+      for (size_t k = 0; k < live; k++) unit_order.push_back(hp[by_len[k]].first_unit + s);
+    }
+  }
+  tm.lap("  chunk: tables");
   // One blob each way (a per-pair call is dominated by the number of HIP calls, not by bytes):
-  //   xin   (H2D):   [ExactPair x n | unit_pair x n_units | symbols]      staged in pinned host memory
+  //   xin   (H2D):   [ExactPair x n | unit_pair x n_units | unit_order x n_units | symbols]   staged in pinned host memory
   //   xzero (memset): [control words: [0] ticket, [32] err, [64 ..) per-pair done counters | boundary rows]
   //   xout  (D2H):   [ExactOut x n | traceback ops]
   auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
-  const size_t in_pairs = 0, in_units = align16(n * sizeof(ExactPair)), in_sym = in_units + align16(n_units * 4);
+  const size_t in_pairs = 0, in_units = align16(n * sizeof(ExactPair)), in_order = in_units + align16(n_units * 4),
+               in_sym = in_order + align16(n_units * 4);
   const size_t in_bytes = in_sym + align16(pool_syms * 2 + 16);
   const size_t ctl_words = 64 + n;
   const size_t z_bnd = align16(ctl_words * 4), z_bytes = z_bnd + align16(std::max<size_t>(bnd_ints * 4, 16));
@@ -330,6 +350,7 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
   uint8_t* const h_in = (uint8_t*)c.h_in.p;
   memcpy(h_in + in_pairs, hp.data(), n * sizeof(ExactPair));
   memcpy(h_in + in_units, unit_pair.data(), n_units * 4);
+  memcpy(h_in + in_order, unit_order.data(), n_units * 4);
   for (const SeqCopy& sc_ : copies) memcpy(h_in + in_sym + sc_.off * 2, sc_.p, (size_t)sc_.len * 2);
   tm.lap("  chunk: stage");
   HIPCK(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, c.stream));
@@ -340,6 +361,7 @@ int run_exact_chunk(const PairSpec* specs, size_t begin, size_t end, Scoring sc,
   w.pairs = (const ExactPair*)(d_in + in_pairs);
   w.outs = (ExactOut*)d_out;
   w.unit_pair = (const uint32_t*)(d_in + in_units);
+  w.unit_order = (const uint32_t*)(d_in + in_order);
   w.n_units = (uint32_t)n_units;
   w.n_pairs = (uint32_t)n;
   w.rpl = rpl;
