@@ -233,3 +233,47 @@ def test_other_scorings_like_the_worker_fallback_chain(oracle, sc):
                 e["score"], e["max_x"], e["max_y"], e["q"], e["t"]), (i, len(targets[i]))
     finally:
         db.close()
+
+
+def test_chained_units_in_every_scheduling_regime(oracle, monkeypatch):
+    """A database whose groups span several 16-strip units (targets of ~1 kb) with 16-wave workgroups, under every
+    ticket order the library can choose: one lane (each unit trails its producer with an adjacent ticket), a few
+    lanes, and the default (one lane per group, the producer has finished).  The scores must not depend on it."""
+    import numpy as np
+    import dlsa_amd
+    from dlsa_amd import bridge
+    rng = random.Random(11)
+    nrng = np.random.default_rng(11)
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    q = _rnd(rng, 700)
+    n = 6000                                   # 47 groups x ~63 strips > 2048 strips: 16-wave workgroups
+    lens = nrng.integers(900, 1101, size=n)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    flat = lut[nrng.integers(0, 4, size=int(offs[-1]), dtype=np.uint8)].copy()
+    qb = np.frombuffer(q.encode(), dtype=np.uint8)
+    for i in (7, 3000, 5999):                  # homologs that cross unit boundaries (columns 200..800)
+        o = int(offs[i]) + 200
+        flat[o:o + 600] = qb[50:650]
+    tgt = lambda i: flat[int(offs[i]):int(offs[i + 1])].tobytes().decode()  # noqa: E731
+    sc = (-1, 2, -1)
+    s = dlsa_amd.AlignmentScore(sc[1], sc[2], sc[0])
+    db = bridge.Database(flat=flat, offsets=offs)
+    try:
+        ref = None
+        for lanes in ("1", "3", "40", None):
+            if lanes is None:
+                monkeypatch.delenv("SW_HIP_SCORE_LANES", raising=False)
+            else:
+                monkeypatch.setenv("SW_HIP_SCORE_LANES", lanes)
+            got = np.array(db.scores(q, s))
+            if ref is None:
+                ref = got
+                for i in [7, 3000, 5999] + random.Random(12).sample(range(n), 60):
+                    assert int(got[i]) == oracle.align("lowmem", q, tgt(i), *sc)["score"], i
+            else:
+                assert np.array_equal(ref, got), lanes
+            hits = db.search_topk(q, s, 3)
+            assert sorted(h["target_index"] for h in hits) == [7, 3000, 5999]
+    finally:
+        db.close()
