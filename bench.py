@@ -43,6 +43,11 @@ SEED = 0xD15A
 # corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes); counters cannot be read from inside
 # this process, so the figure is only attached when the shape is the profiled one.
 TRAFFIC_DEFAULT_BYTES = 6.3164e9 + 2 * 3.1593e9
+# Executed packed-i16 lane operations per cell on the default workload, from the same PMC passes:
+# SQ_INSTS_VALU 3.7188e10 wave-instructions x 64 lanes x 2 halves / 1e12 cells.  The algorithmic count the
+# roofline convention uses is 6 per cell; the kernel gets by with fewer (the saturating subtract
+# is also the max with 0, the running maximum is taken on every second column), which is why `frac` can pass 1.
+EXECUTED_OPS_PER_CELL_DEFAULT = 3.7188e10 * 128 / 1e12
 
 
 def synth(rng, n, length):
@@ -151,6 +156,7 @@ def main():
     if rank == 0:
         k_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
         achieved = cells_per_rank * OPS_PER_CELL / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        default_shape = (Q_LEN, T_LEN, n_targets) == (10_000, 1_000, N_TARGETS)  # the shape the PMC passes ran on
         out = {
             "metric": "GCUPS (whole node) at 1/2/4/8 MI355X; % of packed-int16 VALU peak",
             "value": value, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -162,11 +168,14 @@ def main():
                        "parallelism": f"targets sharded over {world} GPU(s), top-k gather"},
             "roofline": {"bound": "valu-int16", "achieved": achieved, "peak": PEAK_TOPS, "unit": "T i16-op/s",
                          "frac": achieved / PEAK_TOPS,
-                         "traffic": (TRAFFIC_DEFAULT_BYTES if (Q_LEN, T_LEN, n_targets) == (10_000, 1_000, N_TARGETS)
-                                     else None),
+                         "traffic": TRAFFIC_DEFAULT_BYTES if default_shape else None,
                          "kernel": "sw_score_kernel", "kernel_ms": k_ms,
+                         "executed": ({"ops_per_cell": EXECUTED_OPS_PER_CELL_DEFAULT,
+                                       "achieved": achieved * EXECUTED_OPS_PER_CELL_DEFAULT / OPS_PER_CELL,
+                                       "frac": achieved * EXECUTED_OPS_PER_CELL_DEFAULT / OPS_PER_CELL / PEAK_TOPS}
+                                      if default_shape else None),
                          "note": "6 algorithmic i16 ops/cell x Q*T cells per launch / HIP-event kernel time; "
-                                 "the kernel executes 4.5 packed instructions per 2 cells"},
+                                 "the kernel executes 4.76 i16 lane-ops per cell (`executed`), so frac can pass 1"},
             "top_hit": (dict(zip(shard.RECORD_FIELDS, last[0])) if last else None),
         }
         if world == 1 and not args.no_cpu_baseline:
