@@ -69,9 +69,6 @@ def cells4(code, r0, hl):
     ]
 
 
-NO_NOPS = "--no-nops" in sys.argv  # timing experiment only: results are WRONG without the wait states
-
-
 def body(code, parity):
     left, diag = (f"v{L0}", f"v{D0}") if parity == 0 else (f"v{L1}", f"v{D1}")
     out = [f"v_pk_add_i16 v{D}, {diag}, {tab(code, 0)} clamp"]
@@ -129,9 +126,7 @@ def main():
     # ring geometry must match sw_score.hip: D slots x B rows x 256 bytes per wave
     Dslots, B = 3, 12  # defaults of sw_score.hip (the asm text itself does not depend on them; B must be even)
     lines = generate()
-    if NO_NOPS:
-        lines = [ln for ln in lines if ln != "s_nop 0"]
-    with open(os.path.join(here, "sw_score_asm_nonops.inc" if NO_NOPS else "sw_score_asm.inc"), "w") as f:
+    with open(os.path.join(here, "sw_score_asm.inc"), "w") as f:
         f.write("// GENERATED by gen_score_asm.py -- do not edit.  Row loop of sw_score_kernel (gfx950).\n")
         f.write(f"#define SW_SCORE_ASM_D {Dslots}\n#define SW_SCORE_ASM_B {B}\n")
         f.write("#define SW_SCORE_ROWS_ASM \\\n")
