@@ -29,7 +29,7 @@ namespace swhip {
 
 namespace {
 
-constexpr int kMaxRPL = 4;  // rows per lane: 4, 2 or 1, chosen per launch (ExactWork::rpl)
+// rows per lane (RPL): 4, 2 or 1, chosen per launch (ExactWork::rpl)
 
 __device__ __forceinline__ int dpp_wave_shr1(int fill_lane0, int v) {
   // lane i <- lane i-1; lane 0 keeps `fill_lane0` (bound_ctrl = 0)
