@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsw_hip.so")
 SOURCES = ["sw_exact.hip", "sw_score.hip", "sw_topk.hip", "sw_lib.cpp", "sw_worker.cpp"]
-HEADERS = [os.path.join(CSRC, "sw_internal.h"), os.path.join(HERE, "..", "include", "sw.h"),
+HEADERS = [os.path.join(CSRC, "sw_internal.h"), os.path.join(CSRC, "sw_score_asm.inc"), os.path.join(CSRC, "gen_score_asm.py"), os.path.join(HERE, "..", "include", "sw.h"),
            os.path.join(HERE, "..", "include", "sw_hip.h"), os.path.join(HERE, "..", "include", "sw_worker.h")]
 
 
@@ -31,7 +31,14 @@ def needs_build():
 EXTRA = {"sw_score.hip": ["-mllvm", "-structurizecfg-skip-uniform-regions=true"]}
 
 
+def check_generated():
+    """sw_score_asm.inc is generated and committed: a generator that was edited without regenerating must not
+    ship a stale row loop."""
+    subprocess.check_call([sys.executable, os.path.join(CSRC, "gen_score_asm.py"), "--check"])
+
+
 def build(force=False, verbose=False):
+    check_generated()
     if not force and not needs_build():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

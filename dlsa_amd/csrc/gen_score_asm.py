@@ -121,19 +121,61 @@ def generate():
     return o
 
 
+def is_valu(ln):
+    return ln.startswith("v_")
+
+
+def counts():
+    """Instruction counts of ONE query row of one strip (16 columns x 2 targets per lane), read off the generated
+    text so that measurement code (sw_hip_last_stats, bench.py) never carries a hand-copied constant: packed VALU
+    instructions of a row body, the other VALU instructions of the loop per row (address increments), s_nops."""
+    b = body(0, 0)
+    assert all(len(body(c, p)) == len(b) for c in range(4) for p in range(2))
+    packed = sum(1 for ln in b if ln.startswith("v_pk_"))
+    snop = sum(1 for ln in b if ln.startswith("s_nop"))
+    loop = generate()
+    top = loop.index("Ltop_%=:")
+    two_rows = loop[top:loop.index("Lexit_%=:")]
+    other = sum(1 for ln in two_rows if is_valu(ln) and not ln.startswith("v_pk_"))
+    # the loop text holds 4 bodies per row parity; `other` counts the per-2-row address increments plus one
+    # v_add per row parity that only executes when the row is also stored to global memory
+    aux_always = sum(1 for ln in two_rows if ln.startswith("v_add_u32_e32 %[addr]") or ln.startswith("v_add_u32_e32 %[waddr]"))
+    aux_store = sum(1 for ln in two_rows if ln.startswith("v_add_u32_e32 %[goff]"))
+    assert other == aux_always + aux_store and aux_always == 2 and aux_store == 2
+    return {"packed": packed, "snop": snop, "aux_x2": aux_always, "store": aux_store // 2}
+
+
+def render(Dslots=3, B=12):
+    """the text of sw_score_asm.inc (ring geometry must match sw_score.hip: D slots x B rows x 256 bytes per wave;
+    the asm text itself does not depend on them; B must be even)"""
+    lines = generate()
+    c = counts()
+    out = ["// GENERATED by gen_score_asm.py -- do not edit.  Row loop of sw_score_kernel (gfx950).\n",
+           f"#define SW_SCORE_ASM_D {Dslots}\n#define SW_SCORE_ASM_B {B}\n",
+           "// executed instructions per query row of one strip (wave-instructions; 16 columns x 128 targets):\n",
+           f"#define SW_SCORE_ASM_PACKED_PER_ROW {c['packed']}   /* v_pk_* of one row body */\n",
+           f"#define SW_SCORE_ASM_AUX_PER_2ROWS {c['aux_x2']}    /* address increments, once per two rows */\n",
+           f"#define SW_SCORE_ASM_STORE_PER_ROW {c['store']}    /* extra VALU of a row that is also stored to HBM */\n",
+           f"#define SW_SCORE_ASM_SNOP_PER_ROW {c['snop']}\n",
+           "#define SW_SCORE_ROWS_ASM \\\n"]
+    for ln in lines:
+        out.append(f'  "{ln}\\n\\t" \\\n')
+    out.append('  ""\n')
+    return "".join(out), len(lines)
+
+
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    # ring geometry must match sw_score.hip: D slots x B rows x 256 bytes per wave
-    Dslots, B = 3, 12  # defaults of sw_score.hip (the asm text itself does not depend on them; B must be even)
-    lines = generate()
+    text, n = render()
+    if "--check" in sys.argv:  # used by build.py and tests/test_cpu_generated_asm.py
+        with open(os.path.join(here, "sw_score_asm.inc")) as f:
+            if f.read() != text:
+                print("sw_score_asm.inc is stale: run python dlsa_amd/csrc/gen_score_asm.py", file=sys.stderr)
+                sys.exit(1)
+        return
     with open(os.path.join(here, "sw_score_asm.inc"), "w") as f:
-        f.write("// GENERATED by gen_score_asm.py -- do not edit.  Row loop of sw_score_kernel (gfx950).\n")
-        f.write(f"#define SW_SCORE_ASM_D {Dslots}\n#define SW_SCORE_ASM_B {B}\n")
-        f.write("#define SW_SCORE_ROWS_ASM \\\n")
-        for ln in lines:
-            f.write(f'  "{ln}\\n\\t" \\\n')
-        f.write('  ""\n')
-    print(len(lines), "asm lines")
+        f.write(text)
+    print(n, "asm lines")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,193 @@
+// dlsa_amd/csrc/sw_host.h -- host-side internals shared by the translation units of libsw_hip.so
+// (sw_lib.cpp: contexts, exact driver, per-pair ABI; sw_db.cpp: resident database, score pass, top-k;
+// sw_node.cpp: several GPUs behind one handle; sw_worker.cpp: the worker-side callers).
+// Not installed; the public contract is include/*.h.
+#pragma once
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/sw_worker.h"
+#include "sw_internal.h"
+
+namespace swhip {
+
+// ---- errors --------------------------------------------------------------------------------------------
+int fail(int code, const std::string& msg);  // records the calling thread's message, returns code
+const std::string& last_error_string();
+#define HIPCK(expr)                                                                                  \
+  do {                                                                                               \
+    hipError_t e__ = (expr);                                                                         \
+    if (e__ != hipSuccess)                                                                           \
+      return ::swhip::fail(SW_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));            \
+  } while (0)
+
+// ---- device memory that grows on demand, or a fixed window of the no-allocation scratch ------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool fixed = false;  // a window of the static scratch array: never allocates, never frees (sw_db_scores_noalloc)
+  int ensure(size_t bytes);
+  void bind_fixed(void* ptr, size_t bytes) {
+    p = ptr;
+    cap = bytes;
+    fixed = true;
+  }
+  void release();
+};
+// pinned host staging memory (async copies from pageable memory are staged by the runtime, synchronously);
+// in fixed mode a window of plain host memory reserved when the context was set up
+struct HostBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  bool fixed = false;
+  int ensure(size_t bytes);
+  void bind_fixed(void* ptr, size_t bytes) {
+    p = ptr;
+    cap = bytes;
+    fixed = true;
+  }
+  void release();
+};
+
+// Everything a submission needs beyond its inputs and outputs.  A context owns two: `ws` grows on demand
+// (hipMalloc), `na` is carved out of the per-device static scratch array once, at set-up.
+struct Workspace {
+  DevBuf xin, xzero, xout, dirs, xrecs;                    // exact path (run_exact_chunk)
+  HostBuf h_in, h_out;                                     // ... its host staging buffers
+  DevBuf sel_hist, sel_ctr, sel_rerun, sel_cand, sel_tie;  // device-side top-k selection
+  DevBuf qwords, slot_scores, gbound, ticket, prog, units; // score path
+  void release();
+};
+
+constexpr int kMaxDevices = 64;
+
+struct Context {
+  std::mutex mu;  // one GPU submission at a time per device; the ABI is entered from many threads
+  int device = 0;
+  int cus = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+  Workspace ws;
+  sw_kernel_stats stats{};
+  size_t scratch_budget = (size_t)8 << 30;
+};
+
+// The context of a device (created on first use; device < 0: the process's default device, which sw_hip_init
+// selects and which is 0 otherwise).  On failure *out is null and the error is recorded.
+int ctx_get(int device, Context** out);
+// Locks a context for one submission and makes its device current for the calling thread (HIP's current device
+// is per thread; the ABI is entered from many threads).
+struct CtxLock {
+  Context* c = nullptr;
+  int rc = SW_OK;
+  std::unique_lock<std::mutex> lk;
+  explicit CtxLock(int device);
+  explicit CtxLock(Context* ctx);
+};
+
+// ---- text -> symbols ----------------------------------------------------------------------------------------
+// A sequence as the algorithm sees it: Unicode scalars truncated to u16 (`*x as u16`,
+// rust/src/algorithm/mod.rs:78,224).  Pure-ASCII input (the normal case: DNA) never materialises code points.
+struct Decoded {
+  const char* src = nullptr;  // borrowed
+  bool ascii = true;
+  std::vector<uint32_t> cps;  // only when !ascii: for re-encoding the alignment
+  std::vector<uint16_t> sym;
+  uint32_t cp(size_t i) const { return ascii ? (uint32_t)(unsigned char)src[i] : cps[i]; }
+};
+bool decode(const char* s, size_t n, Decoded& d);
+bool decode(const char* s, Decoded& d);
+inline uint32_t roundup64(uint32_t v) { return (v + 63u) / 64u * 64u; }
+Scoring to_scoring(AlignmentScores s);
+
+// ---- exact path driver ----------------------------------------------------------------------------------------
+struct PairSpec {
+  const uint16_t* q;
+  uint32_t Q;
+  const uint16_t* t;
+  uint32_t T;
+  int path;
+  // optional: small dense ids of the two sequences within the submission (equal id <=> same sequence); lets the
+  // driver upload every distinct sequence once without hashing 10^5 pointers.  UINT32_MAX: look the pointer up.
+  uint32_t qid = UINT32_MAX, tid = UINT32_MAX;
+};
+struct PairOut {
+  int32_t score = 0;
+  uint32_t bx = 0, bj = 0;
+  size_t ops_off = 0;  // traceback ops (last alignment column first) at arena[ops_off .. ops_off + nops)
+  uint32_t nops = 0;
+};
+struct PathParams {
+  uint32_t Tlim, T0, phaseQp, straight;
+};
+PathParams resolve_path(int path, uint32_t Q, uint32_t T);
+bool ring_div_by_zero(int path, uint32_t Q, uint32_t T, Scoring sc);
+// Caller holds the context's lock.
+int run_exact(Context& c, Workspace& ws, const PairSpec* specs, size_t n, Scoring sc, bool want_trace, PairOut* outs,
+              std::vector<uint8_t>* arena = nullptr);
+
+// ---- result strings ---------------------------------------------------------------------------------------------
+char* str_alloc(size_t n);
+void str_free(char* p);
+// Builds the two aligned strings (str_alloc'ed, NUL-terminated) from the walker's ops.
+bool build_alignment(const Decoded& q, const Decoded& t, const PairOut& o, const uint8_t* ops, char** qa_out,
+                     char** ta_out, size_t* qa_len);
+
+// host threads for the byte loops around a big submission (decoding, string assembly, packing); an exception
+// inside a helper thread is caught there and re-raised (as bad_alloc) by the caller
+void parallel_ranges_impl(size_t n, unsigned nt, void (*fn)(void*, size_t, size_t), void* arg);
+template <class F>
+void parallel_ranges(size_t n, size_t work, F&& f) {
+  unsigned nt = 16;
+  if (work < (1u << 20) || n < 32) nt = 1;
+  parallel_ranges_impl(n, nt, [](void* a, size_t lo, size_t hi) { (*(F*)a)(lo, hi); }, (void*)&f);
+}
+
+// SW_HIP_TRACE=1: host stage times of big submissions on stderr (development aid)
+struct StageTimer {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  explicit StageTimer(size_t n) : on(n >= 1000 && getenv("SW_HIP_TRACE")), t0(std::chrono::steady_clock::now()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sw_hip] %-22s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
+// ---- resident database (sw_db.cpp) ------------------------------------------------------------------------------
+struct QueryPrep {
+  Decoded d;
+  bool acgt = true;
+  std::vector<uint32_t> qwords;
+};
+bool prep_query(const char* query, QueryPrep& qp);
+struct TopEntry {
+  int32_t score;
+  uint32_t target;
+};
+// score descending, then database index ascending (declared replacement of the reference's arrival-order
+// ties, cli/__main__.py:171)
+inline bool top_before(const TopEntry& a, const TopEntry& b) {
+  return a.score != b.score ? a.score > b.score : a.target < b.target;
+}
+// one reported hit to be aligned: query index, database index, the score the selection saw
+struct HitRef {
+  uint32_t query;
+  uint32_t target;
+  int32_t score;
+};
+// Phase A of a search: per query the k best (score, target) of this database.  Takes the database's context lock.
+int db_topk_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring sc, size_t k, std::vector<std::vector<TopEntry>>& tops);
+// Phase B: end cell + traceback of the listed hits in one exact submission; hits_out[i] describes refs[i]
+// (target_index = the database-local index; strings owned by the caller).  Takes the context lock.
+int db_align_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring sc, const std::vector<HitRef>& refs, sw_hit* hits_out);
+Context* db_context(sw_db* db);
+
+}  // namespace swhip

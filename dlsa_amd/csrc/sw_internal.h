@@ -143,6 +143,9 @@ struct ScoreParams {
   const uint32_t* qwords;     // query, 2 bits per residue, 16 per dword (row-block aligned)
   uint32_t Q;
   uint32_t n_units;
+  uint32_t n_elems;           // strips in the stream   } bounds the kernel checks the tables against
+  uint32_t n_groups;          //                        } (an inconsistent table is an error code, not a fault)
+  uint32_t n_slots;           // 128 * n_groups         }
   int32_t* slot_scores;       // per slot: best H over the effective domain (32767 = saturated); zeroed
   uint32_t* gbound;           // ring of inter-unit boundary columns: ring_slots * gbound_stride dwords
   uint64_t gbound_stride;     // dwords per ring slot (Q_pad * 64)

@@ -1350,6 +1350,9 @@ int score_pass_locked(sw_db* db, const QueryPrep& qp, Scoring sc) {
   p.elem_group = db->d_elem_group;
   p.units = db->d_units;
   p.n_units = db->n_units;
+  p.n_elems = db->n_elems;
+  p.n_groups = (uint32_t)db->groups.size();
+  p.n_slots = (uint32_t)db->slot_target.size();
   p.slot_scores = (int32_t*)c.slot_scores.p;
   p.gbound = (uint32_t*)c.gbound.p;
   p.gbound_stride = gb_stride;
@@ -1374,7 +1377,15 @@ int score_pass_locked(sw_db* db, const QueryPrep& qp, Scoring sc) {
 // after the stream has been synchronised: error word + kernel time of the last score pass
 int score_pass_finish_locked(sw_db* db, uint32_t Q, uint32_t kerr) {
   Context& c = g_ctx;
-  if (kerr) return fail(SW_E_HIP, "score kernel: a dependency wait timed out");
+  if (kerr) {
+    static const char* const what[] = {"", "a wait for another workgroup's boundary column ran out of time",
+                                       "a wait for a neighbouring wave ran out of time",
+                                       "the unit queue of a workgroup stalled", "inconsistent unit table entry",
+                                       "boundary ring slot smaller than the query", "strip with a bad group index",
+                                       "strip outside its group / chained unit without a producer"};
+    return fail(SW_E_HIP, std::string("score kernel: ") + (kerr < 8 ? what[kerr] : "unknown error") + " (code " +
+                              std::to_string(kerr) + ")");
+  }
   float ms = 0;
   HIPCK(hipEventElapsedTime(&ms, c.ev0, c.ev1));
   c.stats.score_kernel_ms += ms;
