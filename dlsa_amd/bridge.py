@@ -141,6 +141,32 @@ def lib():
     L.sw_hip_test_units.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.POINTER(C.c_uint32)]
     L.sw_hip_test_units.restype = C.c_int64
+    # one process, several GPUs
+    L.sw_node_create.argtypes = [C.POINTER(C.c_int), C.c_int]
+    L.sw_node_create.restype = C.c_void_p
+    L.sw_node_free.argtypes = [C.c_void_p]
+    L.sw_node_free.restype = None
+    L.sw_node_shards.argtypes = [C.c_void_p]
+    L.sw_node_shards.restype = C.c_int
+    L.sw_shard_plan.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.c_int, C.POINTER(C.c_uint32)]
+    L.sw_shard_plan.restype = C.c_int
+    L.sw_node_db_create.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint64]
+    L.sw_node_db_create.restype = C.c_void_p
+    L.sw_node_db_free.argtypes = [C.c_void_p]
+    L.sw_node_db_free.restype = None
+    L.sw_node_db_size.argtypes = [C.c_void_p]
+    L.sw_node_db_size.restype = C.c_uint64
+    L.sw_node_db_shards.argtypes = [C.c_void_p]
+    L.sw_node_db_shards.restype = C.c_int
+    L.sw_node_db_shard_info.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.sw_node_db_shard_info.restype = C.c_int
+    L.sw_node_search_topk_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.c_size_t, CScores, C.c_int,
+                                            C.POINTER(CHit), C.POINTER(C.c_int)]
+    L.sw_node_search_topk_batch.restype = C.c_int
+    L.sw_node_last_stats.argtypes = [C.c_void_p, C.c_int, C.POINTER(CStats)]
+    L.sw_node_last_stats.restype = C.c_int
+    L.sw_node_benchmark_cups.argtypes = [C.c_void_p]
+    L.sw_node_benchmark_cups.restype = C.c_float
     # include/sw_worker.h
     L.sw_execute_work.argtypes = [C.POINTER(CWorkPackage), C.POINTER(CAlignmentDetail)]
     L.sw_execute_work.restype = C.c_int
@@ -162,6 +188,13 @@ def lib():
     L.sw_db_from_fasta.restype = C.c_void_p
     L.sw_write_query_results.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(CHit), C.c_int]
     L.sw_write_query_results.restype = C.c_int
+    L.sw_synth_lengths.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+    L.sw_synth_lengths.restype = C.c_int
+    L.sw_synth_fill.argtypes = [C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p,
+                                C.POINTER(C.c_uint64)]
+    L.sw_synth_fill.restype = C.c_int
+    L.sw_synth_write_fasta.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.sw_synth_write_fasta.restype = C.c_int
     _lib = L
     return L
 
@@ -303,6 +336,145 @@ class Database:
             out.append([self._hit(hits[q * k + i]) for i in range(nh[q])])
             L.sw_hits_free(C.cast(C.byref(hits, q * k * C.sizeof(CHit)), C.POINTER(CHit)), nh[q])
         return out
+
+
+def synth_lengths(seed, n, min_len, max_len, first=0):
+    """sw_synth_lengths: lengths of sequences first .. first + n - 1 of the seeded synthetic set."""
+    import numpy as np
+    out = np.zeros(max(n, 1), dtype=np.uint32)
+    rc = lib().sw_synth_lengths(seed, first, n, min_len, max_len, out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if rc != 0:
+        raise SwHipError(f"sw_synth_lengths failed ({rc}): {last_error()}")
+    return out[:n]
+
+
+def synth(seed, n, min_len, max_len, indices=None):
+    """The seeded restatement of utils/generate_synthetic_data.py:7-12 (sw_synth_*): returns (flat uint8 array,
+    offsets uint64 array) of sequences `indices` (default 0 .. n-1) of the set (seed, min_len, max_len)."""
+    import numpy as np
+    L = lib()
+    if indices is None:
+        lens = synth_lengths(seed, n, min_len, max_len)
+        idx_p = None
+    else:
+        indices = np.ascontiguousarray(indices, dtype=np.uint64)
+        n = len(indices)
+        if min_len == max_len:
+            lens = np.full(n, min_len, dtype=np.uint32)
+        else:  # lengths of arbitrary indices: one call per contiguous run would do; simply generate them all once
+            hi = int(indices.max()) + 1 if n else 0
+            lens = synth_lengths(seed, hi, min_len, max_len)[indices.astype(np.int64)]
+        idx_p = indices.ctypes.data_as(C.POINTER(C.c_uint64))
+    offsets = np.zeros(n + 1, dtype=np.uint64)
+    offsets[1:] = np.cumsum(lens, dtype=np.uint64)
+    flat = np.empty(max(int(offsets[-1]), 1), dtype=np.uint8)
+    rc = L.sw_synth_fill(seed, idx_p, n, min_len, max_len, flat.ctypes.data_as(C.c_void_p),
+                         offsets.ctypes.data_as(C.POINTER(C.c_uint64)))
+    if rc != 0:
+        raise SwHipError(f"sw_synth_fill failed ({rc}): {last_error()}")
+    return flat[:int(offsets[-1])], offsets
+
+
+def shard_plan(offsets, n_shards):
+    """sw_shard_plan: shard of every sequence of a database given by its n + 1 offsets (host arithmetic, no GPU)."""
+    import numpy as np
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    out = np.zeros(max(n, 1), dtype=np.uint32)
+    rc = lib().sw_shard_plan(offsets.ctypes.data_as(C.POINTER(C.c_uint64)), n, n_shards,
+                             out.ctypes.data_as(C.POINTER(C.c_uint32)))
+    if rc != 0:
+        raise SwHipError(f"sw_shard_plan failed ({rc}): {last_error()}")
+    return out[:n]
+
+
+class Node:
+    """sw_node: the GPUs one worker process drives (devices may repeat: logical shards on one GPU)."""
+
+    def __init__(self, devices=None, n_devices=0):
+        L = lib()
+        if devices is None:
+            self._h = L.sw_node_create(None, n_devices)
+        else:
+            arr = (C.c_int * len(devices))(*devices)
+            self._h = L.sw_node_create(arr, len(devices))
+        if not self._h:
+            raise SwHipError(f"sw_node_create failed: {last_error()}")
+        self.n_shards = L.sw_node_shards(self._h)
+
+    def benchmark_cups(self):
+        return float(lib().sw_node_benchmark_cups(self._h))
+
+    def close(self):
+        if self._h:
+            lib().sw_node_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NodeDatabase:
+    """sw_node_db: one database sharded by target over the GPUs of a Node."""
+
+    def __init__(self, node, seqs=None, flat=None, offsets=None):
+        import numpy as np
+        L = lib()
+        if seqs is not None:
+            bs = [_b(s) for s in seqs]
+            flat = b"".join(bs)
+            offsets = np.zeros(len(bs) + 1, dtype=np.uint64)
+            offsets[1:] = np.cumsum([len(s) for s in bs], dtype=np.uint64)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.n = len(offsets) - 1
+        buf = flat if isinstance(flat, bytes) else flat.tobytes()
+        self._node = node
+        self._h = L.sw_node_db_create(node._h, buf, offsets.ctypes.data_as(C.POINTER(C.c_uint64)), self.n)
+        if not self._h:
+            raise SwHipError(f"sw_node_db_create failed: {last_error()}")
+
+    def shard_info(self):
+        L = lib()
+        out = []
+        for s in range(L.sw_node_db_shards(self._h)):
+            dev, n, res = C.c_int(), C.c_uint64(), C.c_uint64()
+            L.sw_node_db_shard_info(self._h, s, C.byref(dev), C.byref(n), C.byref(res))
+            out.append(dict(device=dev.value, n_targets=n.value, residues=res.value))
+        return out
+
+    def search_topk_batch(self, queries, score, k):
+        L = lib()
+        n = len(queries)
+        qs = (C.c_char_p * max(n, 1))(*[_b(q) for q in queries])
+        hits = (CHit * max(n * k, 1))()
+        nh = (C.c_int * max(n, 1))()
+        rc = L.sw_node_search_topk_batch(self._h, qs, n, score.c(), k, hits, nh)
+        if rc != 0:
+            raise SwHipError(f"sw_node_search_topk_batch failed ({rc}): {last_error()}")
+        out = []
+        for q in range(n):
+            out.append([Database._hit(hits[q * k + i]) for i in range(nh[q])])
+            L.sw_hits_free(C.cast(C.byref(hits, q * k * C.sizeof(CHit)), C.POINTER(CHit)), nh[q])
+        return out
+
+    def last_stats(self, shard):
+        st = CStats()
+        lib().sw_node_last_stats(self._h, shard, C.byref(st))
+        return {k: getattr(st, k) for k, _ in CStats._fields_}
+
+    def close(self):
+        if self._h:
+            lib().sw_node_db_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def last_stats():

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/sw_worker.h"
@@ -90,6 +91,17 @@ struct CtxLock {
   explicit CtxLock(Context* ctx);
 };
 
+// Error returns between queued asynchronous work and its synchronisation must not leave copies in flight that read
+// or write buffers the caller is about to release (stack variables, vectors, the staging buffers of the next
+// submission): every function that queues work holds one of these; on the success path the stream is idle already.
+struct StreamDrain {
+  hipStream_t s;
+  explicit StreamDrain(hipStream_t st) : s(st) {}
+  ~StreamDrain() { (void)hipStreamSynchronize(s); }
+  StreamDrain(const StreamDrain&) = delete;
+  StreamDrain& operator=(const StreamDrain&) = delete;
+};
+
 // ---- text -> symbols ----------------------------------------------------------------------------------------
 // A sequence as the algorithm sees it: Unicode scalars truncated to u16 (`*x as u16`,
 // rust/src/algorithm/mod.rs:78,224).  Pure-ASCII input (the normal case: DNA) never materialises code points.
@@ -145,7 +157,8 @@ template <class F>
 void parallel_ranges(size_t n, size_t work, F&& f) {
   unsigned nt = 16;
   if (work < (1u << 20) || n < 32) nt = 1;
-  parallel_ranges_impl(n, nt, [](void* a, size_t lo, size_t hi) { (*(F*)a)(lo, hi); }, (void*)&f);
+  using Fn = typename std::remove_reference<F>::type;
+  parallel_ranges_impl(n, nt, [](void* a, size_t lo, size_t hi) { (*(Fn*)a)(lo, hi); }, (void*)&f);
 }
 
 // SW_HIP_TRACE=1: host stage times of big submissions on stderr (development aid)
@@ -189,5 +202,10 @@ int db_topk_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring sc, size
 // (target_index = the database-local index; strings owned by the caller).  Takes the context lock.
 int db_align_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring sc, const std::vector<HitRef>& refs, sw_hit* hits_out);
 Context* db_context(sw_db* db);
+sw_db* db_create_on(Context* ctx, const char* flat, const uint64_t* offsets, uint64_t n);
+sw_db* db_create_owned(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off);
+const std::string& db_flat(const sw_db* db);
+const std::vector<uint64_t>& db_offsets(const sw_db* db);
+double benchmark_cups_on(Context* ctx);  // cells per second of the batch path on one device
 
 }  // namespace swhip

@@ -12,12 +12,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <memory>
 #include <string>
 #include <vector>
 
-#include "../../include/sw_worker.h"
-#include "sw_internal.h"
+#include "sw_host.h"
 
 using swhip::set_last_error;
 
@@ -325,6 +325,109 @@ int sw_write_query_results(const char* results_dir, const char* query_id, const 
     return SW_E_ARG;
   }
   return SW_OK;
+  });
+}
+
+}  // extern "C"
+
+// ---- synthetic sequences (utils/generate_synthetic_data.py:7-12 with a fixed PRNG) ---------------------------------
+namespace {
+struct SynthRng {  // xoshiro256** seeded by splitmix64 of (seed, sequence index)
+  uint64_t s[4];
+  static uint64_t splitmix(uint64_t& x) {
+    x += 0x9E3779B97F4A7C15ull;
+    uint64_t z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  }
+  SynthRng(uint64_t seed, uint64_t index) {
+    uint64_t x = seed ^ (index * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull);
+    for (auto& v : s) v = splitmix(x);
+  }
+  static uint64_t rotl(uint64_t v, int k) { return (v << k) | (v >> (64 - k)); }
+  uint64_t next() {
+    const uint64_t r = rotl(s[1] * 5, 7) * 9, t = s[1] << 17;
+    s[2] ^= s[0];
+    s[3] ^= s[1];
+    s[1] ^= s[2];
+    s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl(s[3], 45);
+    return r;
+  }
+};
+// random.randint(min_size, max_size): the first draw of the sequence's generator
+inline uint32_t synth_length(SynthRng& g, uint32_t min_len, uint32_t max_len) {
+  const uint64_t range = (uint64_t)max_len - min_len + 1;
+  return min_len + (uint32_t)(((g.next() >> 32) * range) >> 32);
+}
+// random.choices(["A", "T", "C", "G"], k=seq_length): 32 residues per 64-bit draw
+inline void synth_residues(SynthRng& g, char* dst, uint32_t len) {
+  static const char kAlpha[4] = {'A', 'T', 'C', 'G'};
+  uint32_t i = 0;
+  while (i < len) {
+    uint64_t v = g.next();
+    for (int k = 0; k < 32 && i < len; k++, v >>= 2) dst[i++] = kAlpha[v & 3];
+  }
+}
+bool synth_args_ok(uint32_t min_len, uint32_t max_len) { return min_len <= max_len && max_len < 0x7fffff00u; }
+}  // namespace
+
+extern "C" {
+
+int sw_synth_lengths(uint64_t seed, uint64_t first, uint64_t n, uint32_t min_len, uint32_t max_len, uint32_t* lengths) {
+  return swhip::guarded<int>(SW_E_NOMEM, [&]() -> int {
+    if ((!lengths && n) || !synth_args_ok(min_len, max_len)) return swhip::fail(SW_E_ARG, "sw_synth_lengths: bad argument");
+    swhip::parallel_ranges(n, n * 64, [&](size_t lo, size_t hi) {
+      for (size_t k = lo; k < hi; k++) {
+        SynthRng g(seed, first + k);
+        lengths[k] = synth_length(g, min_len, max_len);
+      }
+    });
+    return SW_OK;
+  });
+}
+
+int sw_synth_fill(uint64_t seed, const uint64_t* indices, uint64_t n, uint32_t min_len, uint32_t max_len, char* flat,
+                  const uint64_t* offsets) {
+  return swhip::guarded<int>(SW_E_NOMEM, [&]() -> int {
+    if ((!flat && n) || !offsets || !synth_args_ok(min_len, max_len)) return swhip::fail(SW_E_ARG, "sw_synth_fill: bad argument");
+    std::atomic<bool> bad{false};
+    swhip::parallel_ranges(n, n ? (size_t)(offsets[n] - offsets[0]) + n * 64 : 0, [&](size_t lo, size_t hi) {
+      for (size_t k = lo; k < hi; k++) {
+        SynthRng g(seed, indices ? indices[k] : k);
+        const uint32_t len = synth_length(g, min_len, max_len);
+        if (offsets[k + 1] < offsets[k] || offsets[k + 1] - offsets[k] != len) {
+          bad = true;
+          return;
+        }
+        synth_residues(g, flat + offsets[k], len);
+      }
+    });
+    if (bad) return swhip::fail(SW_E_ARG, "sw_synth_fill: offsets do not match the generated lengths");
+    return SW_OK;
+  });
+}
+
+int sw_synth_write_fasta(const char* path, uint64_t seed, uint64_t n, uint32_t min_len, uint32_t max_len) {
+  return swhip::guarded<int>(SW_E_NOMEM, [&]() -> int {
+    if (!path || !synth_args_ok(min_len, max_len)) return swhip::fail(SW_E_ARG, "sw_synth_write_fasta: bad argument");
+    FILE* fp = fopen(path, "wb");
+    if (!fp) return swhip::fail(SW_E_ARG, std::string("sw_synth_write_fasta: cannot open ") + path + ": " + strerror(errno));
+    std::string seq;
+    for (uint64_t i = 0; i < n; i++) {
+      SynthRng g(seed, i);
+      const uint32_t len = synth_length(g, min_len, max_len);
+      seq.resize(len);
+      synth_residues(g, &seq[0], len);
+      fprintf(fp, ">seq%llu\n", (unsigned long long)(i + 1));
+      fwrite(seq.data(), 1, seq.size(), fp);
+      fputc('\n', fp);
+    }
+    const bool bad = ferror(fp) != 0;
+    if (fclose(fp) != 0 || bad) return swhip::fail(SW_E_ARG, std::string("sw_synth_write_fasta: write error on ") + path);
+    return SW_OK;
   });
 }
 

@@ -1,49 +1,61 @@
-"""Sharding a target database over the GPUs of one node and merging the per-GPU top-k.
+"""One process per GPU (bench.py under torchrun): sharding ONE target database over the ranks with the library's
+own sharder and merging the per-rank top-k of a whole query batch with a single all_gather.
 
 The reference distributes work by (query, target) pair over worker processes
 (master/work_package/_scheduler/proportional_work_scheduler.py:30-55) and computes top-k client-side after
-every pair's result has travelled worker -> master -> CLI (cli/__main__.py:153-173).  Here one process per GPU
-owns a contiguous shard of the targets; the only exchange is an all_gather of k fixed-size hit records per
-rank (RCCL when the tensors are on the GPUs, gloo on CPUs in the tests), merged by
-(score descending, global target index ascending) -- the declared replacement of the reference's
-arrival-order ties.
+every pair's result has travelled worker -> master -> CLI (cli/__main__.py:153-173).  Here rank r owns the targets
+`sw_shard_plan` (include/sw_hip.h; residue-balanced within length buckets) assigns to shard r -- the same plan the
+in-process multi-GPU handle (sw_node_*) uses -- and the only exchange is ONE all_gather of n_queries x k fixed-size
+records per rank (RCCL when the tensors are on the GPUs, gloo on CPUs in the tests), merged by
+(score descending, global target index ascending): the declared replacement of the reference's arrival-order ties
+(SURVEY.md A10).
 """
+import numpy as np
 import torch
 
-
-def shard_range(n_targets, rank, world):
-    """Contiguous, balanced split: rank r owns [first, first + count)."""
-    base, rem = divmod(n_targets, world)
-    first = rank * base + min(rank, rem)
-    return first, base + (1 if rank < rem else 0)
-
+from . import bridge
 
 RECORD_FIELDS = ("score", "target_index", "max_x", "max_y")
 
 
-def merge_topk(local_hits, k, first_index=0, dist=None, device="cpu"):
-    """local_hits: list of dicts with score / target_index (shard-local) / max_x / max_y, already the
-    rank's own top-k.  Returns the global top-k as a list of [score, global_index, max_x, max_y]."""
-    rec = torch.full((k, 4), -1, dtype=torch.int64)
-    for i, h in enumerate(local_hits[:k]):
-        # max_x / max_y are uint64 in the ABI (2^64-1 = no hit); stored as their int64 bit pattern
-        rec[i] = torch.tensor([h["score"], first_index + h["target_index"],
-                               _as_i64(h["max_x"]), _as_i64(h["max_y"])], dtype=torch.int64)
-    n_valid = torch.tensor([min(len(local_hits), k)], dtype=torch.int64)
+def plan(offsets, world):
+    """shard_of[i] for every target of the global database (host arithmetic in libsw_hip.so, no GPU)."""
+    return bridge.shard_plan(offsets, world)
+
+
+def local_targets(shard_of, rank):
+    """global indices of the targets rank `rank` owns, ascending: local index i <-> global index result[i]"""
+    return np.flatnonzero(np.asarray(shard_of) == rank).astype(np.int64)
+
+
+def merge_topk_batch(local_hits, k, global_index, dist=None, device="cpu"):
+    """local_hits[q]: this rank's own top-k for query q (dicts with score / target_index (shard-local) / max_x /
+    max_y).  Returns, per query, the global top-k as [score, global_index, max_x, max_y] rows.  One collective."""
+    nq = len(local_hits)
+    rec = torch.full((max(nq, 1), k, 4), -1, dtype=torch.int64)
+    for q, hits in enumerate(local_hits):
+        for i, h in enumerate(hits[:k]):
+            # max_x / max_y are uint64 in the ABI (2^64-1 = no hit); stored as their int64 bit pattern.  A row
+            # whose global index is -1 is padding (fewer than k hits).
+            rec[q, i, 0] = h["score"]
+            rec[q, i, 1] = int(global_index[h["target_index"]])
+            rec[q, i, 2] = _as_i64(h["max_x"])
+            rec[q, i, 3] = _as_i64(h["max_y"])
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        rec, n_valid = rec.to(device), n_valid.to(device)
+        rec = rec.to(device)
         world = dist.get_world_size()
-        allrec = [torch.empty_like(rec) for _ in range(world)]
-        allcnt = [torch.empty_like(n_valid) for _ in range(world)]
-        dist.all_gather(allrec, rec)
-        dist.all_gather(allcnt, n_valid)
-        rows = []
-        for r, c in zip(allrec, allcnt):
-            rows += r[: int(c.item())].cpu().tolist()
+        allrec = torch.empty((world * rec.shape[0], k, 4), dtype=rec.dtype, device=rec.device)  # rank-major concat
+        dist.all_gather_into_tensor(allrec, rec)
+        rows = allrec.cpu().numpy().reshape(world, rec.shape[0], k, 4)   # one device-to-host copy
     else:
-        rows = rec[: int(n_valid.item())].tolist()
-    rows.sort(key=lambda r: (-r[0], r[1]))
-    return rows[:k]
+        rows = rec.numpy()[None]
+    out = []
+    for q in range(nq):
+        cand = rows[:, q].reshape(-1, 4)
+        cand = cand[cand[:, 1] >= 0]
+        order = np.lexsort((cand[:, 1], -cand[:, 0]))[:k]
+        out.append(cand[order].tolist())
+    return out
 
 
 def _as_i64(v):

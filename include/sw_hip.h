@@ -24,6 +24,7 @@ extern "C" {
 #define SW_E_HIP -3      /* a HIP runtime call failed */
 #define SW_E_NOMEM -4
 #define SW_E_DOMAIN -5   /* scoring outside the supported domain for this entry point */
+#define SW_E_LIMIT -6    /* the input exceeds a stated size limit of this entry point */
 
 /* which reference entry point's semantics to reproduce */
 #define SW_PATH_LOW_MEMORY 0 /* rust/src/algorithm/mod.rs:204-445 incl. the T < 2Q dispatch at :213 */
@@ -98,6 +99,35 @@ int sw_db_search_topk_batch(sw_db *db, const char *const *queries, size_t n_quer
 int sw_db_scores(sw_db *db, const char *query, struct AlignmentScores scores, int32_t *scores_out);
 void sw_hits_free(struct sw_hit *hits, int n_hits);
 
+/* ---- one worker process, several GPUs -----------------------------------------------------
+ * The reference spreads a job over worker PROCESSES by (query, target) pair
+ * (master/work_package/_scheduler/proportional_work_scheduler.py:30-55) and sorts every pair's score client-side
+ * (cli/__main__.py:153-173).  A node handle lets ONE worker process drive all GPUs of its machine: the target
+ * database is sharded by target, balanced by residues within length buckets; every GPU searches its shard on its
+ * own host thread, stream and scratch and keeps its own top-k; the only cross-GPU traffic is a host merge of
+ * n_queries x k records by (score descending, database index ascending); end cells and tracebacks are computed
+ * for the merged hits only, on the GPU that owns the target.  Results are identical to sw_db_search_topk_batch on
+ * the unsharded database. */
+typedef struct sw_node sw_node;
+typedef struct sw_node_db sw_node_db;
+/* devices[i] = HIP device of shard i; a device may appear more than once (logical shards: tests, or a rehearsal
+ * of the N-GPU path on one GPU).  devices == NULL: devices 0 .. n-1 of the machine (n_devices <= 0: all). */
+sw_node *sw_node_create(const int *devices, int n_devices);
+void sw_node_free(sw_node *node);
+int sw_node_shards(const sw_node *node);
+/* The sharder alone (host arithmetic, no GPU): shard_of[i] = shard of sequence i for a database given by n + 1
+ * offsets.  Sequences are length-sorted, cut into tiles of up to 128 consecutive ones (one wave's worth of lanes)
+ * and the tiles dealt longest-first to the shard with the fewest residues so far. */
+int sw_shard_plan(const uint64_t *offsets, uint64_t n, int n_shards, uint32_t *shard_of);
+sw_node_db *sw_node_db_create(sw_node *node, const char *flat, const uint64_t *offsets, uint64_t n);
+void sw_node_db_free(sw_node_db *db);
+uint64_t sw_node_db_size(const sw_node_db *db);
+int sw_node_db_shards(const sw_node_db *db);
+int sw_node_db_shard_info(const sw_node_db *db, int shard, int *device, uint64_t *n_targets, uint64_t *residues);
+/* sw_db_search_topk_batch over all shards; target_index of a hit is the index as passed to sw_node_db_create. */
+int sw_node_search_topk_batch(sw_node_db *db, const char *const *queries, size_t n_queries,
+                              struct AlignmentScores scores, int k, struct sw_hit *hits, int *n_hits);
+
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------------- */
 struct sw_kernel_stats {
   double score_kernel_ms;   /* HIP-event time of the last inter-task score-kernel launch(es), on the
@@ -114,6 +144,11 @@ int sw_hip_last_stats(struct sw_kernel_stats *out);
  * master/api_models/worker.py:7-16): cells per second of the batch path on synthetic DNA, as a
  * float32-representable INTEGER-valued number (the master's field is a pydantic int). */
 float sw_hip_benchmark_cups(void);
+/* The same for a whole node: every distinct device of the handle runs the benchmark at the same time and the
+ * figures are added -- the number a one-process-per-node GPU worker registers with the master. */
+float sw_node_benchmark_cups(sw_node *node);
+/* sw_hip_last_stats for one shard of a node database (its device's last submission). */
+int sw_node_last_stats(const sw_node_db *db, int shard, struct sw_kernel_stats *out);
 
 /* ---- test hook (no GPU needed) ------------------------------------------------------------------------ */
 /* The four integers by which one plain Smith-Waterman reproduces a reference entry point for a pair of

@@ -82,6 +82,21 @@ void sw_fasta_free(sw_fasta *f);
 /* Uploads the records as a resident database (sw_db_create on the parsed sequences). */
 sw_db *sw_db_from_fasta(const sw_fasta *f);
 
+/* ---- synthetic sequences ------------------------------------------------------------------------------------------
+ * utils/generate_synthetic_data.py:7-12 restated with a fixed PRNG (the script uses Python's unseeded `random`):
+ * sequence i (0-based; its FASTA id is "seq{i+1}") has a length uniform in [min_len, max_len] and i.i.d. uniform
+ * residues over "ATCG" (the script's alphabet order).  Length and residues derive from (seed, i) alone
+ * (splitmix64 -> xoshiro256**), so any subset -- one GPU's shard -- can be generated on its own and two machines
+ * produce the same bytes. */
+/* lengths[k] = length of sequence first + k, for k < n */
+int sw_synth_lengths(uint64_t seed, uint64_t first, uint64_t n, uint32_t min_len, uint32_t max_len, uint32_t *lengths);
+/* Writes the residues of sequences indices[0..n) (indices == NULL: 0 .. n-1) back to back into flat;
+ * offsets (n + 1 entries, offsets[k+1] - offsets[k] = the sequence's length) says where each one goes. */
+int sw_synth_fill(uint64_t seed, const uint64_t *indices, uint64_t n, uint32_t min_len, uint32_t max_len, char *flat,
+                  const uint64_t *offsets);
+/* The script's file format: ">seq{i}\n<sequence>\n" for i = 1 .. n. */
+int sw_synth_write_fasta(const char *path, uint64_t seed, uint64_t n, uint32_t min_len, uint32_t max_len);
+
 /* Appends the hits of one query to <results_dir>/<query_id>.txt in the CLI's format
  * (cli/__main__.py:175-194): per hit ">target\nAlignment: <query alignment>\nLength: <n>\nScore: <s>\n\n";
  * the directory is created if missing, an existing file is appended to.  target_ids[i] names hits[i]. */

@@ -1,6 +1,6 @@
-"""Multi-GPU path on CPU: world_size 2 and 3 over gloo.  The database is sharded by target, every rank
-keeps a local top-k, the only exchange is the all_gather of k records; the merged list must equal the top-k of
-the whole table under (score desc, global index asc)."""
+"""Multi-GPU path on CPU: world_size 2 and 3 over gloo.  ONE database is sharded by target with the library's
+sharder, every rank keeps a local top-k per query, the only exchange is ONE all_gather of n_queries x k records; the
+merged lists must equal the top-k of the whole table under (score desc, global index asc)."""
 import json
 import os
 import subprocess
@@ -12,17 +12,24 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world,n,k", [(2, 1001, 5), (3, 64, 7), (2, 3, 5)])
-def test_sharded_topk_merge(tmp_path, world, n, k):
+@pytest.mark.parametrize("world,n,k,nq", [(2, 1001, 5, 4), (3, 64, 7, 2), (2, 3, 5, 1)])
+def test_sharded_topk_merge(tmp_path, world, n, k, nq):
+    from dlsa_amd import build
+    build.build()
     out = tmp_path / "merged.json"
     port = 29500 + (os.getpid() % 500) + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(HERE, "_gloo_topk_worker.py"), str(out), str(n), str(k)]
+           os.path.join(HERE, "_gloo_topk_worker.py"), str(out), str(n), str(k), str(nq)]
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    subprocess.run(cmd, check=True, timeout=240, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-    merged = json.loads(out.read_text())
-    scores = np.random.default_rng(1234).integers(0, 50, size=n)
-    exp = sorted(range(n), key=lambda i: (-int(scores[i]), i))[:k]
-    assert [m[1] for m in merged] == exp
-    assert [m[0] for m in merged] == [int(scores[i]) for i in exp]
+    r = subprocess.run(cmd, timeout=240, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    res = json.loads(out.read_text())
+    assert res["collectives"] == 1          # the whole query batch travels in one all_gather
+    rng = np.random.default_rng(1234)
+    rng.integers(0, 300, size=n)
+    scores = rng.integers(0, 50, size=(nq, n))
+    for q in range(nq):
+        exp = sorted(range(n), key=lambda i: (-int(scores[q, i]), i))[:k]
+        assert [m[1] for m in res["merged"][q]] == exp
+        assert [m[0] for m in res["merged"][q]] == [int(scores[q, i]) for i in exp]

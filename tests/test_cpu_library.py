@@ -99,15 +99,44 @@ def test_path_dispatch_matches_clean_model(L, oracle):
     assert params(0, len(q), len(t)) == (64, 64, 0, 0)   # T >= 2Q: ring path, no quirk
 
 
-def test_shard_ranges_cover_the_database():
-    from dlsa_amd import shard
-    for n in (0, 1, 7, 8, 100000, 1000003):
-        for world in (1, 2, 3, 8):
-            spans = [shard.shard_range(n, r, world) for r in range(world)]
-            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
-            for (f0, c0), (f1, _) in zip(spans, spans[1:]):
-                assert f0 + c0 == f1
-            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+def test_sharder_covers_and_balances(L):
+    """sw_shard_plan (host arithmetic): every target in exactly one shard, residue totals balanced within 2 % on
+    the C3 length distribution (10^6 targets of 200..5000 nt over 8 GPUs), whole lane tiles of
+    similar lengths per shard, deterministic, and sane on tiny and degenerate databases."""
+    import numpy as np
+    from dlsa_amd import bridge
+    rng = np.random.default_rng(3)
+    lens = rng.integers(200, 5001, size=1_000_000)
+    offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens)
+    for shards in (2, 3, 8):
+        so = bridge.shard_plan(offs, shards)
+        assert so.min() == 0 and so.max() == shards - 1
+        tot = np.bincount(so, weights=lens, minlength=shards)
+        assert (tot.max() - tot.min()) / tot.mean() < 0.02, tot
+        cnt = np.bincount(so, minlength=shards)
+        assert cnt.sum() == len(lens)
+        assert np.array_equal(so, bridge.shard_plan(offs, shards))          # deterministic
+        # every shard holds targets from every length bucket (a shard of only-short targets would finish early)
+        for s in range(shards):
+            mine = lens[so == s]
+            assert mine.min() < 300 and mine.max() > 4900
+        # tiles: in length-sorted order, runs of 128 consecutive targets share a shard
+        order = np.argsort(-lens, kind="stable")
+        runs = so[order][: (len(lens) // 128) * 128].reshape(-1, 128)
+        assert (runs == runs[:, :1]).all()
+    # tiny and degenerate inputs
+    assert list(bridge.shard_plan(np.array([0], dtype=np.uint64), 4)) == []
+    one = bridge.shard_plan(np.array([0, 10], dtype=np.uint64), 3)
+    assert list(one) == [0]
+    offs = np.arange(0, 70, 10, dtype=np.uint64)                               # 6 equal targets over 3 shards
+    so = bridge.shard_plan(offs, 3)
+    assert sorted(np.bincount(so, minlength=3)) == [2, 2, 2]
+    zeros = np.zeros(11, dtype=np.uint64)                                       # empty sequences still spread
+    assert len(set(bridge.shard_plan(zeros, 2))) == 2
+    bad = np.array([0, 5, 3], dtype=np.uint64)
+    with pytest.raises(bridge.SwHipError):
+        bridge.shard_plan(bad, 2)
 
 
 def test_score_unit_tables_keep_their_invariants(L):
