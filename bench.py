@@ -1,16 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- GCUPS of the Smith-Waterman database search on N MI355X of one node.
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on): 1 query (10 kb DNA)
-vs 100,000 targets (1 kb) PER GPU, match 2 / mismatch 1 / gap 1, top-k 5.  Synthetic sequences with the
-distribution of the reference's utils/generate_synthetic_data.py:7-12 (i.i.d. uniform A/C/G/T), seeded.
+Workloads (BASELINE.json configs; sequences from the library's seeded restatement of the reference's
+utils/generate_synthetic_data.py:7-12, sw_synth_*: i.i.d. uniform A/T/C/G):
+  c2 (default, the configuration the metric is quoted on): 1 query (10 kb) vs 100,000 targets (1 kb) PER GPU,
+      match 2 / mismatch 1 / gap 1, top-k 5.  Weak scaling: the global database has N x 100,000 targets.
+  c3: 32 queries (1 kb) vs ONE database of 1,000,000 targets of 200..5000 nt, sharded over the N GPUs.  Strong
+      scaling: the total work is fixed.
 
-One "step" = one full search of the rank's resident database shard through the C ABI
-(sw_db_search_topk): query upload, inter-task packed-int16 score kernel over all pairs, int32 re-runs,
-top-k selection, exact end-cell + traceback kernels for the 5 hits, results back on the host; with
-N > 1 the ranks then exchange their k hit records (one small all_gather over RCCL) and merge them by
-(score desc, global target index asc).  The database shard is already resident in HBM when the timed
-region starts.  Scaling is weak: every rank owns 100,000 targets, no data-path collective.
+One process per GPU.  Every rank derives the same global database description from the seed, asks the library's
+sharder (sw_shard_plan: residue-balanced within length buckets) which targets are its own, generates and uploads
+only those.  One "step" = one search of the whole query batch through the C ABI (sw_db_search_topk_batch): query
+upload, inter-task packed-int16 score kernel over all pairs, int32 re-runs, on-device top-k selection, exact end
+cell + traceback for the rank's hits, results back on the host; with N > 1 the ranks then exchange their
+n_queries x k hit records in ONE all_gather (RCCL) and merge them by (score desc, global target index asc).  The
+shard is already resident in HBM when the timed region starts.
 
 GCUPS = sum over pairs of Q*T (unpadded, as internal/worker/worker_rust_benchmark.go:31 counts cells)
 / wall seconds / 1e9, wall = max over ranks between two barriers.
@@ -30,57 +34,111 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-Q_LEN = 10_000
-T_LEN = 1_000
-N_TARGETS = 100_000
 TOP_K = 5
 MATCH, MISMATCH, GAP = 2, -1, -1           # as the worker passes them (worker_impl.go:126-127)
-OPS_PER_CELL = 6                            # algorithmic i16 ops per cell
 PEAK_TOPS = 78.6                            # 256 CU x 64 lanes/clk x 2 (packed) x 2.4 GHz, BASELINE.md 3
+SURVEY_OPS_PER_CELL = 6                     # the survey's count of algorithmic i16 ops per cell
+USEFUL_OPS_PER_CELL = 4.5                   # what this formulation needs at least
 SEED = 0xD15A
-# HBM-side bytes of one score-kernel launch on the default workload, from the PMC passes committed under
-# profiles/ (r01_pmc_summary.csv: WRITE_SIZE 6.32e6 KB + 2 x FETCH_SIZE 3.16e6 KB, the gfx950 half-count
-# corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes); counters cannot be read from inside
-# this process, so the figure is only attached when the shape is the profiled one.
-TRAFFIC_DEFAULT_BYTES = 6.3164e9 + 2 * 3.1593e9
-# Executed packed-i16 lane operations per cell on the default workload, from the same PMC passes:
-# SQ_INSTS_VALU 3.7188e10 wave-instructions x 64 lanes x 2 halves / 1e12 cells.  The algorithmic count the
-# roofline convention uses is 6 per cell; the kernel gets by with fewer (the saturating subtract
-# is also the max with 0, the running maximum is taken on every second column), which is why `frac` can pass 1.
-EXECUTED_OPS_PER_CELL_DEFAULT = 3.7188e10 * 128 / 1e12
+WORKLOADS = {
+    # name: (queries, query length, targets (per GPU for weak / total for strong), min len, max len, scaling)
+    "c2": dict(n_queries=1, q_len=10_000, targets=100_000, t_min=1_000, t_max=1_000, scaling="weak",
+               config="BASELINE.json configs[1]"),
+    "c3": dict(n_queries=32, q_len=1_000, targets=1_000_000, t_min=200, t_max=5_000, scaling="strong",
+               config="BASELINE.json configs[2]"),
+}
 
 
-def synth(rng, n, length):
-    """n sequences of `length` i.i.d. uniform A/C/G/T (utils/generate_synthetic_data.py:11)."""
-    lut = np.frombuffer(b"ATCG", dtype=np.uint8)
-    flat = lut[rng.integers(0, 4, size=n * length, dtype=np.uint8)]
-    offsets = np.arange(n + 1, dtype=np.uint64) * np.uint64(length)
-    return flat, offsets
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(query, flat, offsets, n_pairs, threads):
-    """The oracle (CPU restatement of the reference's Rust path, driven like the Go worker) on a bounded
-    sample of the same workload.  Reported baseline only."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def _oracle_leg(name, queries, targets, scores, threads, note):
+    """The oracle (CPU restatement of the reference's Rust path, driven like the Go worker: static chunks, one
+    fallback-chain call per pair) on a list of pairs.  Reported baseline only."""
     import oracle_lib
-    targets = [flat[int(offsets[i]):int(offsets[i + 1])].tobytes() for i in range(n_pairs)]
-    secs, cells, _ = oracle_lib.bench_pairs([query] * n_pairs, targets, GAP, MATCH, MISMATCH, threads)
-    return {"value": cells / secs / 1e9, "unit": "GCUPS", "cores": threads, "kind": "port",
-            "sample": f"first {n_pairs} of the {N_TARGETS} pairs (10 kb x 1 kb each), {threads} threads, "
-                      f"static chunks, one find_alignment_low_memory restatement call per pair, {secs:.2f} s"}
+    gap, match, miss = scores
+    secs, cells, _ = oracle_lib.bench_pairs(queries, targets, gap, match, miss, threads)
+    return {"shape": name, "value": cells / secs / 1e9, "unit": "GCUPS", "cores": threads, "kind": "port",
+            "pairs": len(queries), "seconds": round(secs, 3), "sample": note}
+
+
+def cpu_baseline(bridge, main_query, main_flat, main_offsets, n_total):
+    """Bounded samples of the bench workload and of the other BASELINE.json shapes on this box's host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    threads = max(1, min(16, (os.cpu_count() or 2)) - 1)
+    S = (GAP, MATCH, MISMATCH)
+    seqs = lambda flat, off, idx: [flat[int(off[i]):int(off[i + 1])].tobytes() for i in idx]  # noqa: E731
+    n_main = 72 * threads
+    main = _oracle_leg("c2", [main_query] * n_main, seqs(main_flat, main_offsets, range(n_main)), S, threads,
+                       f"first {n_main} of the {n_total} pairs (10 kb x 1 kb each), {threads} threads, static chunks, "
+                       f"one find_alignment_low_memory restatement call per pair")
+    others = []
+    # C1, full: 1 query (1 kb) vs 1000 targets of 900..1100 nt
+    q, _ = bridge.synth(SEED + 10, 1, 1000, 1000)
+    f, o = bridge.synth(SEED + 11, 1000, 900, 1100)
+    others.append(_oracle_leg("c1", [q.tobytes()] * 1000, seqs(f, o, range(1000)), S, threads, "full: 1 x 1 kb vs 1000 x ~1 kb"))
+    # C3, sub-sampled: 32 queries (1 kb) vs 10^6 targets of 200..5000 nt -> the first 12 targets for every query
+    qf, qo = bridge.synth(SEED + 20, 32, 1000, 1000)
+    f, o = bridge.synth(SEED + 21, 150, 200, 5000)
+    qs = seqs(qf, qo, range(32))
+    others.append(_oracle_leg("c3", [x for x in qs for _ in range(150)], seqs(f, o, range(150)) * 32, S, threads,
+                              "sub-sampled: 32 queries x the first 150 of 10^6 targets (factor 1 / 6 667 of the pairs)"))
+    # C5, sub-sampled: 150 nt queries vs 150 nt reads
+    qf, qo = bridge.synth(SEED + 30, 40, 150, 150)
+    f, o = bridge.synth(SEED + 31, 10000, 150, 150)
+    qs = seqs(qf, qo, range(40))
+    others.append(_oracle_leg("c5", [x for x in qs for _ in range(10000)], seqs(f, o, range(10000)) * 40, S, threads,
+                              "sub-sampled: 40 of 1000 queries x 10 000 of 10^7 reads (factor 1 / 25 000 of the pairs)"))
+    # the worker's capacity benchmark shape (worker_rust_benchmark.go:9-23): one pair, one thread, match 1 / -1 / -2
+    others.append(_oracle_leg("capacity", [b"TTTTCA" + b"A" * 4096], [b"TTTTCA" + b"T" * (1 << 18)], (-2, 1, -1), 1,
+                              "full: the benchmark's first pair, 4102 x 262150, one thread (ring-buffer path)"))
+    main["cpu_model"] = cpu_model()
+    main["others"] = others
+    return main
+
+
+def load_pmc_traffic(key):
+    """HBM bytes per score-kernel launch from the committed PMC passes (profiles/r02_pmc.json), if the workload is
+    one that was profiled; counters cannot be read from inside this process."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+            return json.load(f).get(key)
+    except (OSError, ValueError):
+        return None
 
 
 def main():
-    global Q_LEN, T_LEN
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--targets", type=int, default=N_TARGETS, help="targets per GPU (default = the named workload)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2")
+    ap.add_argument("--targets", type=int, default=None, help="targets per GPU (c2) / in total (c3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tlen", type=int, default=T_LEN, help="target length (default = the named workload)")
-    ap.add_argument("--qlen", type=int, default=Q_LEN, help="query length (default = the named workload)")
+    ap.add_argument("--tlen", type=int, default=None, help="fixed target length (default: the workload's range)")
+    ap.add_argument("--qlen", type=int, default=None, help="query length (default: the workload's)")
+    ap.add_argument("--queries", type=int, default=None, help="number of queries (default: the workload's)")
+    ap.add_argument("--node-shards", type=int, default=0,
+                    help="ONE process drives S logical shards through sw_node_* (the in-process multi-GPU path; on a "
+                         "one-GPU box all shards sit on device 0)")
     args = ap.parse_args()
+    wl = dict(WORKLOADS[args.workload])
+    if args.targets:
+        wl["targets"] = args.targets
+    if args.tlen:
+        wl["t_min"] = wl["t_max"] = args.tlen
+    if args.qlen:
+        wl["q_len"] = args.qlen
+    if args.queries:
+        wl["n_queries"] = args.queries
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -103,18 +161,36 @@ def main():
         torch.cuda.set_device(local_rank)
 
     import dlsa_amd
-    from dlsa_amd import bridge
+    from dlsa_amd import bridge, shard
     L = bridge.lib()
     rc = L.sw_hip_init(local_rank)
     if rc != 0:
         raise SystemExit(f"sw_hip_init({local_rank}) failed: {bridge.last_error()}")
 
-    n_targets = args.targets
-    Q_LEN, T_LEN = args.qlen, args.tlen
-    # the query is the same on every rank; every rank owns its own shard of targets
-    query = synth(np.random.default_rng(SEED), 1, Q_LEN)[0].tobytes()
-    flat, offsets = synth(np.random.default_rng(SEED + 1 + rank), n_targets, T_LEN)
-    db = bridge.Database(flat=flat, offsets=offsets)
+    # ---- the global database, described by (seed, n, length range); this rank's shard of it
+    weak = wl["scaling"] == "weak"
+    n_global = wl["targets"] * (world if weak else 1)
+    q_flat, q_off = bridge.synth(SEED, wl["n_queries"], wl["q_len"], wl["q_len"])
+    queries = [q_flat[int(q_off[i]):int(q_off[i + 1])].tobytes() for i in range(wl["n_queries"])]
+    if wl["t_min"] == wl["t_max"]:
+        lens = np.full(n_global, wl["t_min"], dtype=np.uint32)
+    else:
+        lens = bridge.synth_lengths(SEED + 1, n_global, wl["t_min"], wl["t_max"])
+    g_off = np.zeros(n_global + 1, dtype=np.uint64)
+    g_off[1:] = np.cumsum(lens, dtype=np.uint64)
+    if world > 1:
+        mine = shard.local_targets(shard.plan(g_off, world), rank)
+    else:
+        mine = np.arange(n_global, dtype=np.int64)
+    flat, offsets = bridge.synth(SEED + 1, 0, wl["t_min"], wl["t_max"], indices=mine)
+    t0 = time.perf_counter()
+    node = ndb = db = None
+    if args.node_shards > 0:
+        node = bridge.Node(devices=[local_rank] * args.node_shards)
+        ndb = bridge.NodeDatabase(node, flat=flat, offsets=offsets)
+    else:
+        db = bridge.Database(flat=flat, offsets=offsets)
+    db_build_s = time.perf_counter() - t0
     score = dlsa_amd.AlignmentScore(MATCH, MISMATCH, GAP)
     dev = torch.device("cpu") if rehearsal else torch.device("cuda", local_rank)
 
@@ -124,65 +200,96 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    from dlsa_amd import shard
-    first_index = rank * n_targets  # weak scaling: every rank owns n_targets targets of the global database
-
     def step():
-        hits = db.search_topk(query, score, TOP_K)
-        st = bridge.last_stats()
-        merged = shard.merge_topk(hits, TOP_K, first_index, dist, dev)
+        if ndb is not None:
+            hits = ndb.search_topk_batch(queries, score, TOP_K)
+            st = ndb.last_stats(0)
+        else:
+            hits = db.search_topk_batch(queries, score, TOP_K)
+            st = bridge.last_stats()
+        merged = shard.merge_topk_batch(hits, TOP_K, mine, dist, dev)
         return merged, st
 
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = []
+    stats = []
     last = None
     for _ in range(args.steps):
         last, st = step()
-        kernel_ms.append(st["score_kernel_ms"])
+        stats.append(st)
     barrier()
     elapsed = time.perf_counter() - t0
+    my_cells = float(wl["q_len"]) * float(offsets[-1]) * wl["n_queries"]
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed, 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    cells_per_rank = float(Q_LEN) * float(T_LEN) * n_targets
-    total_cells = cells_per_rank * world * args.steps
-    value = total_cells / elapsed / 1e9
+        elapsed = float(tmax[0].item())
+        tsum = torch.tensor([my_cells], dtype=torch.float64, device=dev)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        step_cells = float(tsum.item())
+    else:
+        step_cells = my_cells
+    value = step_cells * args.steps / elapsed / 1e9
 
     if rank == 0:
-        k_ms = float(np.mean(kernel_ms)) if kernel_ms else 0.0
-        achieved = cells_per_rank * OPS_PER_CELL / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
-        default_shape = (Q_LEN, T_LEN, n_targets) == (10_000, 1_000, N_TARGETS)  # the shape the PMC passes ran on
+        # ---- roofline of the dominant kernel (sw_score_kernel), from what THIS run launched and timed:
+        # HIP-event time on the library's stream and the library's own launch counters (include/sw_hip.h)
+        launches = sum(s["score_launches"] for s in stats) or 1
+        k_ms = sum(s["score_kernel_ms"] for s in stats) / launches
+        cells_launch = sum(s["score_cells"] for s in stats) / launches
+        packed, aux2 = stats[-1]["score_packed_per_row"], stats[-1]["score_aux_per_2rows"]
+        wave_instr = (sum(s["score_strip_rows"] for s in stats) * (packed + aux2 / 2.0)
+                      + sum(s["score_chain_rows"] for s in stats)) / launches
+        k_s = k_ms * 1e-3 if k_ms > 0 else float("inf")
+        executed = wave_instr * 128 / k_s / 1e12           # 64 lanes x 2 int16 halves per wave-instruction
+        useful = cells_launch * USEFUL_OPS_PER_CELL / k_s / 1e12
+        survey = cells_launch * SURVEY_OPS_PER_CELL / k_s / 1e12
+        traffic_model = (sum(s["score_chain_rows"] for s in stats) / launches * 256 * 2
+                         + float(offsets[-1]) / 4 + len(mine) * 4)
+        pmc = load_pmc_traffic(f"{args.workload}:{wl['q_len']}x{len(mine)}x{wl['t_min']}-{wl['t_max']}")
+        q_desc = f"{wl['n_queries']} quer{'y' if wl['n_queries'] == 1 else 'ies'} ({wl['q_len']} nt)"
+        t_desc = (f"{wl['t_min']} nt" if wl["t_min"] == wl["t_max"] else f"{wl['t_min']}-{wl['t_max']} nt")
         out = {
             "metric": "GCUPS (whole node) at 1/2/4/8 MI355X; % of packed-int16 VALU peak",
             "value": value, "unit": "GCUPS", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": wl["scaling"],
             "vs_baseline": None, "dtype": "i16 (packed, int32 re-run on saturation)", "data": "synthetic",
-            "config": {"workload": f"1 query ({Q_LEN} nt) vs {n_targets} targets ({T_LEN} nt) per GPU, "
-                                   f"match 2 / mismatch 1 / gap 1, top-k {TOP_K} (BASELINE.json configs[1])",
-                       "pairs_per_gpu": n_targets, "cells_per_gpu_per_step": cells_per_rank,
-                       "parallelism": f"targets sharded over {world} GPU(s), top-k gather"},
-            "roofline": {"bound": "valu-int16", "achieved": achieved, "peak": PEAK_TOPS, "unit": "T i16-op/s",
-                         "frac": achieved / PEAK_TOPS,
-                         "traffic": TRAFFIC_DEFAULT_BYTES if default_shape else None,
-                         "kernel": "sw_score_kernel", "kernel_ms": k_ms,
-                         "executed": ({"ops_per_cell": EXECUTED_OPS_PER_CELL_DEFAULT,
-                                       "achieved": achieved * EXECUTED_OPS_PER_CELL_DEFAULT / OPS_PER_CELL,
-                                       "frac": achieved * EXECUTED_OPS_PER_CELL_DEFAULT / OPS_PER_CELL / PEAK_TOPS}
-                                      if default_shape else None),
-                         "note": "6 algorithmic i16 ops/cell x Q*T cells per launch / HIP-event kernel time; "
-                                 "the kernel executes 4.76 i16 lane-ops per cell (`executed`), so frac can pass 1"},
-            "top_hit": (dict(zip(shard.RECORD_FIELDS, last[0])) if last else None),
+            "config": {"workload": f"{q_desc} vs {wl['targets']} targets ({t_desc}) "
+                                   f"{'per GPU' if weak else 'in total, sharded by target'}, match 2 / mismatch 1 / gap 1, "
+                                   f"top-k {TOP_K} ({wl['config']})",
+                       "name": args.workload, "targets_global": n_global, "targets_rank0": int(len(mine)),
+                       "cells_per_step": step_cells,
+                       "parallelism": (f"one process, {args.node_shards} logical shard(s) via sw_node_*" if ndb is not None else
+                                       f"one database sharded by target over {world} GPU(s) (sw_shard_plan), "
+                                       f"one all_gather of {wl['n_queries']} x {TOP_K} records")},
+            # value_cold: the same step including the one-time sw_db_create of the shard (validation, length sort,
+            # 2-bit packing on host threads, upload); never `value`
+            "value_cold": step_cells / (db_build_s + elapsed / args.steps) / 1e9, "db_build_s": db_build_s,
+            "roofline": {"bound": "valu-int16", "kernel": "sw_score_kernel", "kernel_ms": k_ms,
+                         "launches_per_step": launches / max(1, len(stats)),
+                         # achieved / frac: packed VALU wave-instructions the launch EXECUTED in its row loop
+                         # (strips x rows x instructions per row, counted by the library; instruction counts read off
+                         # the generated loop) x 128 int16 lane-ops / kernel time.  Cannot exceed the issue peak.
+                         "achieved": executed, "peak": PEAK_TOPS, "unit": "T i16-op/s", "frac": executed / PEAK_TOPS,
+                         "useful": {"ops_per_cell": USEFUL_OPS_PER_CELL, "achieved": useful, "frac": useful / PEAK_TOPS},
+                         "survey_convention": {"ops_per_cell": SURVEY_OPS_PER_CELL, "achieved": survey,
+                                               "frac": survey / PEAK_TOPS,
+                                               "note": "SURVEY.md 8d prices a cell at 6 ops; the kernel needs 4.5, so "
+                                                       "this fraction can pass 1 and is kept for continuity only"},
+                         "cells_per_launch": cells_launch, "tcups_kernel": cells_launch / k_s / 1e12,
+                         "wave_instructions_per_launch": wave_instr, "workgroups": stats[-1]["score_workgroups"],
+                         "traffic": (pmc or {}).get("bytes"), "traffic_source": (pmc or {}).get("source"),
+                         "traffic_model": traffic_model},
+            "top_hit": (dict(zip(shard.RECORD_FIELDS, last[0][0])) if last and last[0] else None),
         }
-        if world == 1 and not args.no_cpu_baseline:
-            threads = max(1, min(16, (os.cpu_count() or 2)) - 1)
-            out["cpu_baseline"] = cpu_baseline(query, flat, offsets, 72 * threads, threads)
+        if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
+            out["cpu_baseline"] = cpu_baseline(bridge, queries[0], flat, offsets, len(mine))
         print(json.dumps(out))
-    db.close()
+    for h in (db, ndb, node):
+        if h is not None:
+            h.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -56,7 +56,10 @@ class CAlignmentDetail(C.Structure):  # include/sw_worker.h struct sw_alignment_
 
 class CStats(C.Structure):  # include/sw_hip.h struct sw_kernel_stats
     _fields_ = [("score_kernel_ms", C.c_double), ("exact_kernel_ms", C.c_double), ("score_cells", C.c_uint64),
-                ("exact_cells", C.c_uint64), ("score_launches", C.c_uint32), ("rerun_pairs", C.c_uint32)]
+                ("exact_cells", C.c_uint64), ("score_launches", C.c_uint32), ("rerun_pairs", C.c_uint32),
+                ("score_strip_rows", C.c_uint64), ("score_chain_rows", C.c_uint64),
+                ("score_packed_per_row", C.c_uint32), ("score_aux_per_2rows", C.c_uint32),
+                ("score_workgroups", C.c_uint32), ("pad_", C.c_uint32)]
 
 
 @dataclass
@@ -136,6 +139,12 @@ def lib():
     L.sw_hip_last_stats.argtypes = [C.POINTER(CStats)]
     L.sw_hip_last_stats.restype = C.c_int
     L.sw_hip_benchmark_cups.restype = C.c_float
+    L.sw_hip_struct_size.argtypes = [C.c_int]
+    L.sw_hip_struct_size.restype = C.c_uint32
+    for which, mirror in enumerate((CStats, CHit, CAlignmentDetail, CWorkPackage, CWorkPair)):
+        if L.sw_hip_struct_size(which) != C.sizeof(mirror):
+            raise SwHipError(f"{mirror.__name__} is {C.sizeof(mirror)} bytes, the library's struct "
+                             f"{L.sw_hip_struct_size(which)}: dlsa_amd/bridge.py has fallen behind include/*.h")
     L.sw_hip_path_params.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
     L.sw_hip_path_params.restype = C.c_int
     L.sw_hip_test_units.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,

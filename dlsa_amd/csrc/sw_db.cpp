@@ -36,6 +36,7 @@ struct sw_db {
   // ticket-ordered unit table, rebuilt when the lane count / ring geometry of a search differs (build_units)
   ScoreUnit* d_units = nullptr;
   uint32_t n_units = 0, units_S = 0, units_R = 0, units_W = 0;
+  uint64_t units_chained = 0;        // units that hand their last H column to the next unit through HBM
   std::vector<uint32_t> generic;  // targets scored by the exact kernel only
   uint32_t max_len = 0;
 };
@@ -213,11 +214,18 @@ sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
 // rounds + 7 units, i.e. 8 % of the kernel for 0.2 % of the work).  The units of that partial round are cut into
 // up to four short units (fewer strips): they land on more CUs with one wave per SIMD instead of four, which runs
 // a strip more than twice as fast.
-void build_units(const sw_db* db, uint32_t W, uint32_t S, uint32_t R, uint32_t max_wg, std::vector<ScoreUnit>& units) {
-  struct Lane { uint32_t pos, end, last_ticket; };
-  std::vector<Lane> lanes;
-  const size_t ng = db->groups.size();
-  const uint64_t approx_units = ((uint64_t)db->n_elems + W - 1) / W;
+// The core works on caller-provided arrays and allocates nothing (sw_db_scores_noalloc runs it inside a
+// pre-reserved arena); capacities: lanes >= n_groups, active >= S, slot_reader >= R, units >= units_bound().
+struct UnitLane { uint32_t start, pos, end, last_ticket; };
+size_t units_bound(uint32_t n_elems, size_t n_groups, uint32_t W, uint32_t max_wg) {
+  return (size_t)n_elems / W + n_groups + 3 * (size_t)max_wg + 4;
+}
+// returns the number of units, or -1 if `units_cap` is too small (never with units_bound())
+int64_t build_units_raw(const ScoreGroup* groups, size_t ng, uint32_t n_elems, uint32_t W, uint32_t S, uint32_t R,
+                        uint32_t max_wg, ScoreUnit* units, size_t units_cap, UnitLane* lanes, size_t* active,
+                        uint32_t* slot_reader, uint64_t* chained_out) {
+  size_t n_lanes = 0;
+  const uint64_t approx_units = ((uint64_t)n_elems + W - 1) / W;
   const uint64_t Lmin = std::min<uint64_t>(32, std::max<uint64_t>(2, approx_units / (4ull * S)));
   const uint64_t Lmax = 4 * Lmin + 16;
   for (size_t g = 0; g < ng;) {
@@ -225,50 +233,55 @@ void build_units(const sw_db* db, uint32_t W, uint32_t S, uint32_t R, uint32_t m
     size_t best = g;
     double best_fill = -1;
     for (size_t h = g; h < ng; h++) {
-      cum += db->groups[h].nstrips;
+      cum += groups[h].nstrips;
       const uint64_t u = (cum + W - 1) / W;
       if (u < Lmin && h + 1 < ng) continue;
       const double fill = (double)cum / (double)(u * W);
       if (fill > best_fill) best_fill = fill, best = h;
       if (fill >= 0.995 || u >= Lmax) break;
     }
-    lanes.push_back(Lane{db->groups[g].strip_base, db->groups[best].strip_base + db->groups[best].nstrips, UINT32_MAX});
+    lanes[n_lanes++] = UnitLane{groups[g].strip_base, groups[g].strip_base, groups[best].strip_base + groups[best].nstrips, UINT32_MAX};
     g = best + 1;
   }
-  const std::vector<Lane> lanes0 = lanes;
   // pass 0 counts the units; pass 1 generates them, with short units from ticket `full` on
   uint32_t full = UINT32_MAX, Wtail = W;
+  size_t n_units = 0;
+  uint64_t chained = 0;
   for (int pass = 0; pass < 2; pass++) {
-    lanes = lanes0;
-    units.clear();
-    units.reserve((size_t)approx_units + lanes.size() + 4 * max_wg);
-    std::vector<uint32_t> slot_reader(R, UINT32_MAX);
-    std::vector<size_t> active;
-    size_t next_lane = 0;
-    while (active.size() < S && next_lane < lanes.size()) active.push_back(next_lane++);
-    while (!active.empty()) {
-      for (size_t i = 0; i < active.size();) {
-        Lane& L = lanes[active[i]];
-        const uint32_t t = (uint32_t)units.size();
+    for (size_t l = 0; l < n_lanes; l++) lanes[l].pos = lanes[l].start, lanes[l].last_ticket = UINT32_MAX;
+    n_units = 0;
+    chained = 0;
+    for (uint32_t r = 0; r < R; r++) slot_reader[r] = UINT32_MAX;
+    size_t n_active = 0, next_lane = 0;
+    while (n_active < S && next_lane < n_lanes) active[n_active++] = next_lane++;
+    while (n_active) {
+      for (size_t i = 0; i < n_active;) {
+        UnitLane& L = lanes[active[i]];
+        if (n_units >= units_cap) return -1;
+        const uint32_t t = (uint32_t)n_units;
         ScoreUnit u;
         u.first_elem = L.pos;
         u.count = std::min<uint32_t>(t >= full ? Wtail : W, L.end - L.pos);
         u.dep = L.last_ticket;
         u.reuse = slot_reader[t % R];
         if (u.dep != UINT32_MAX) slot_reader[u.dep % R] = t;
-        units.push_back(u);
+        units[n_units++] = u;
         L.pos += u.count;
         L.last_ticket = t;
         if (L.pos >= L.end) {
-          if (next_lane < lanes.size()) active[i++] = next_lane++;
-          else active.erase(active.begin() + (ptrdiff_t)i);
+          if (next_lane < n_lanes) {
+            active[i++] = next_lane++;
+          } else {
+            for (size_t k = i; k + 1 < n_active; k++) active[k] = active[k + 1];
+            n_active--;
+          }
         } else {
           i++;
         }
       }
     }
     if (pass == 0) {
-      const uint32_t n = (uint32_t)units.size();
+      const uint32_t n = (uint32_t)n_units;
       const uint32_t r = max_wg ? n % max_wg : 0;
       const uint32_t f = r ? std::min<uint32_t>(4, max_wg / r) : 0;
       if (n <= max_wg || f < 2 || W < 8) break;  // no partial round worth cutting
@@ -276,6 +289,35 @@ void build_units(const sw_db* db, uint32_t W, uint32_t S, uint32_t R, uint32_t m
       Wtail = W / f;
     }
   }
+  // units whose last strip is not the last strip of its group hand their H column to the next unit through HBM
+  if (chained_out) {
+    size_t g = 0;
+    for (size_t t = 0; t < n_units; t++) {  // (units of one lane are in stream order but lanes interleave: search per unit)
+      const uint32_t last = units[t].first_elem + units[t].count - 1;
+      size_t lo = 0, hi = ng;
+      while (lo + 1 < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (groups[mid].strip_base <= last) lo = mid;
+        else hi = mid;
+      }
+      g = lo;
+      if (last + 1 < groups[g].strip_base + groups[g].nstrips) chained++;
+    }
+    *chained_out = chained;
+  }
+  return (int64_t)n_units;
+}
+
+void build_units(const sw_db* db, uint32_t W, uint32_t S, uint32_t R, uint32_t max_wg, std::vector<ScoreUnit>& units,
+                 uint64_t* chained_out = nullptr) {
+  const size_t ng = db->groups.size();
+  std::vector<UnitLane> lanes(ng + 1);
+  std::vector<size_t> active(S + 1);
+  std::vector<uint32_t> slot_reader(R);
+  units.resize(units_bound(db->n_elems, ng, W, max_wg));
+  const int64_t n = build_units_raw(db->groups.data(), ng, db->n_elems, W, S, R, max_wg, units.data(), units.size(),
+                                    lanes.data(), active.data(), slot_reader.data(), chained_out);
+  units.resize(n < 0 ? 0 : (size_t)n);
 }
 
 }  // namespace
@@ -351,12 +393,12 @@ bool fast_domain(Scoring sc) {
 
 // Launches the score kernel for one query over the packed part of the database (asynchronous, on the library's
 // stream; ev0/ev1 bracket the kernel).  The per-slot maxima are left in ws.slot_scores.
-int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, Scoring sc) {
-  const uint32_t Q = (uint32_t)qp.d.sym.size();
+int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwords, size_t n_qwords, uint32_t Q,
+                      Scoring sc) {
   const uint32_t nblk = (Q + kScoreB - 1) / kScoreB;
   const size_t Qpad = (size_t)nblk * kScoreB;
   const uint32_t W = (uint32_t)score_waves_per_group(db->n_elems, c.cus);
-  const uint32_t max_wg = (uint32_t)c.cus * (uint32_t)score_workgroups_per_cu((int)W);
+  uint32_t max_wg = (uint32_t)c.cus * (uint32_t)score_workgroups_per_cu((int)W);
   // Active lanes S of the ticket order (build_units): the unit that continues a group is handed out S tickets
   // after its producer.  With S beyond the number of resident workgroups the producer has FINISHED by then and the
   // consumer never waits; a consumer that trails a running producer (small S) costs 5-9 % whatever the lag
@@ -366,36 +408,45 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp,
   const uint32_t nblk16 = (Q + 15) / 16;
   // boundary ring: a workgroup has at most 1 + queue depth units in flight, fewer when a unit is long
   const uint32_t ahead = std::min<uint32_t>(score_queue_depth(), 48 / nblk16 + 1);
-  const uint32_t ring_min = max_wg * (1 + ahead) + 8;
-  const uint64_t ring_fit = 2 * (uint64_t)c.scratch_budget / ((uint64_t)Qpad * 256);
-  uint32_t S = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(8, db->groups.size()));
-  if (ring_fit < (uint64_t)ring_min + S) S = (uint32_t)std::max<uint64_t>(8, ring_fit > ring_min ? ring_fit - ring_min : 0);
-  if (const char* e = getenv("SW_HIP_SCORE_LANES")) S = std::min(16384, std::max(1, atoi(e)));  // experiments
-  const uint32_t ring_slots = S + max_wg * (1 + ahead) + 8;
-  if (db->units_S != S || db->units_R != ring_slots || db->units_W != W || !db->d_units) {
-    std::vector<ScoreUnit> units;
-    build_units(db, W, S, ring_slots, max_wg, units);
-    if (db->d_units) (void)hipFree(db->d_units);
-    db->d_units = nullptr;
-    if (hipMalloc(&db->d_units, std::max<size_t>(units.size(), 1) * sizeof(ScoreUnit)) != hipSuccess)
-      return fail(SW_E_NOMEM, "hipMalloc failed for the unit table");
-    HIPCK(hipMemcpy(db->d_units, units.data(), units.size() * sizeof(ScoreUnit), hipMemcpyHostToDevice));
-    db->n_units = (uint32_t)units.size();
-    db->units_S = S;
-    db->units_R = ring_slots;
-    db->units_W = W;
+  uint32_t S, ring_slots;
+  uint32_t n_units;
+  uint64_t chained = 0;
+  const ScoreUnit* d_units;
+  {
+    const uint32_t ring_min = max_wg * (1 + ahead) + 8;
+    const uint64_t ring_fit = 2 * (uint64_t)c.scratch_budget / ((uint64_t)Qpad * 256);
+    S = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(8, db->groups.size()));
+    if (ring_fit < (uint64_t)ring_min + S) S = (uint32_t)std::max<uint64_t>(8, ring_fit > ring_min ? ring_fit - ring_min : 0);
+    if (const char* e = getenv("SW_HIP_SCORE_LANES")) S = std::min(16384, std::max(1, atoi(e)));  // experiments
+    ring_slots = S + max_wg * (1 + ahead) + 8;
+    if (db->units_S != S || db->units_R != ring_slots || db->units_W != W || !db->d_units) {
+      std::vector<ScoreUnit> units;
+      build_units(db, W, S, ring_slots, max_wg, units, &db->units_chained);
+      if (db->d_units) (void)hipFree(db->d_units);
+      db->d_units = nullptr;
+      if (hipMalloc(&db->d_units, std::max<size_t>(units.size(), 1) * sizeof(ScoreUnit)) != hipSuccess)
+        return fail(SW_E_NOMEM, "hipMalloc failed for the unit table");
+      HIPCK(hipMemcpy(db->d_units, units.data(), units.size() * sizeof(ScoreUnit), hipMemcpyHostToDevice));
+      db->n_units = (uint32_t)units.size();
+      db->units_S = S;
+      db->units_R = ring_slots;
+      db->units_W = W;
+    }
+    n_units = db->n_units;
+    chained = db->units_chained;
+    d_units = db->d_units;
   }
-  const int nwg = (int)std::min<uint32_t>(db->n_units, max_wg);
+  const int nwg = (int)std::min<uint32_t>(n_units, max_wg);
   const size_t gb_stride = Qpad * 64;
   int rc;
-  if ((rc = ws.qwords.ensure(qp.qwords.size() * 4))) return rc;
+  if ((rc = ws.qwords.ensure(n_qwords * 4))) return rc;
   if ((rc = ws.slot_scores.ensure(db->slot_target.size() * 4))) return rc;
   if ((rc = ws.gbound.ensure((size_t)ring_slots * gb_stride * 4))) return rc;
   if ((rc = ws.ticket.ensure(256))) return rc;
-  if ((rc = ws.prog.ensure(std::max<size_t>((size_t)db->n_units * 8, 16)))) return rc;
-  HIPCK(hipMemcpyAsync(ws.qwords.p, qp.qwords.data(), qp.qwords.size() * 4, hipMemcpyHostToDevice, c.stream));
+  if ((rc = ws.prog.ensure(std::max<size_t>((size_t)n_units * 8, 16)))) return rc;
+  HIPCK(hipMemcpyAsync(ws.qwords.p, qwords, n_qwords * 4, hipMemcpyHostToDevice, c.stream));
   HIPCK(hipMemsetAsync(ws.ticket.p, 0, 256, c.stream));
-  HIPCK(hipMemsetAsync(ws.prog.p, 0, std::max<size_t>((size_t)db->n_units * 8, 16), c.stream));
+  HIPCK(hipMemsetAsync(ws.prog.p, 0, std::max<size_t>((size_t)n_units * 8, 16), c.stream));
   HIPCK(hipMemsetAsync(ws.slot_scores.p, 0, db->slot_target.size() * 4, c.stream));
   ScoreParams p{};
   p.words = db->d_words;
@@ -404,8 +455,8 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp,
   p.qwords = (const uint32_t*)ws.qwords.p;
   p.Q = Q;
   p.elem_group = db->d_elem_group;
-  p.units = db->d_units;
-  p.n_units = db->n_units;
+  p.units = d_units;
+  p.n_units = n_units;
   p.n_elems = db->n_elems;
   p.n_groups = (uint32_t)db->groups.size();
   p.n_slots = (uint32_t)db->slot_target.size();
@@ -427,6 +478,12 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp,
   HIPCK(hipEventRecord(c.ev0, c.stream));
   HIPCK(launch_score(p, nwg, (int)W, c.stream));
   HIPCK(hipEventRecord(c.ev1, c.stream));
+  // what this launch executes, for the roofline arithmetic of bench.py (counted, not pasted: every strip of the
+  // stream walks all Q query rows through the generated row loop; a unit that hands its last column to the next
+  // unit also stores those Q rows to HBM, 256 bytes each, and the consumer reads them back once)
+  c.stats.score_strip_rows += (uint64_t)db->n_elems * Q;
+  c.stats.score_chain_rows += chained * Q;
+  c.stats.score_workgroups = (uint32_t)nwg;
   return SW_OK;
 }
 
@@ -503,7 +560,7 @@ int db_scores_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, 
     rerun.resize(db->n);
     std::iota(rerun.begin(), rerun.end(), 0u);
   } else {
-    int rc = score_pass_locked(c, ws, db, qp, sc);
+    int rc = score_pass_locked(c, ws, db, qp.qwords.data(), qp.qwords.size(), (uint32_t)qp.d.sym.size(), sc);
     if (rc) return rc;
     std::vector<int32_t> slot(db->slot_target.size());
     HIPCK(hipMemcpyAsync(slot.data(), ws.slot_scores.p, slot.size() * 4, hipMemcpyDeviceToHost, c.stream));
@@ -545,7 +602,7 @@ int db_topk_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, Sc
   bool device_done = false;
   std::vector<TopEntry> pool;
   if (fast_path(db, qp, sc) && !g_host_topk && k <= 4096) {
-    int rc = score_pass_locked(c, ws, db, qp, sc);
+    int rc = score_pass_locked(c, ws, db, qp.qwords.data(), qp.qwords.size(), (uint32_t)qp.d.sym.size(), sc);
     if (rc) return rc;
     const uint32_t n_slots = (uint32_t)db->slot_target.size();
     if ((rc = ws.sel_hist.ensure(32768 * 4))) return rc;
@@ -635,7 +692,7 @@ int swhip::db_topk_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring s
   tops.assign(qps.size(), {});
   CtxLock L(db->ctx);
   if (L.rc) return L.rc;
-  L.c->stats = sw_kernel_stats{};
+  reset_stats(*L.c);
   for (size_t q = 0; q < qps.size(); q++) {
     const int rc = db_topk_locked(*L.c, L.c->ws, db, qps[q], sc, k, tops[q]);
     if (rc) return rc;
@@ -760,7 +817,7 @@ int sw_db_scores(sw_db* db, const char* query, AlignmentScores as, int32_t* scor
   std::vector<int32_t> scores;
   CtxLock L(db->ctx);
   if (L.rc) return L.rc;
-  L.c->stats = sw_kernel_stats{};
+  reset_stats(*L.c);
   const int rc = db_scores_locked(*L.c, L.c->ws, db, qp, sc, scores);
   if (rc) return rc;
   memcpy(scores_out, scores.data(), scores.size() * sizeof(int32_t));

@@ -81,6 +81,7 @@ struct Context {
 // The context of a device (created on first use; device < 0: the process's default device, which sw_hip_init
 // selects and which is 0 otherwise).  On failure *out is null and the error is recorded.
 int ctx_get(int device, Context** out);
+void reset_stats(Context& c);
 // Locks a context for one submission and makes its device current for the calling thread (HIP's current device
 // is per thread; the ABI is entered from many threads).
 struct CtxLock {

@@ -160,6 +160,8 @@ hipError_t launch_score(const ScoreParams& p, int n_workgroups, int waves, hipSt
 int score_waves_per_group(uint32_t total_strips, int cus);  // waves per workgroup for a database of that many strips
 int score_workgroups_per_cu(int waves);
 uint32_t score_queue_depth();  // units a workgroup may have in flight
+// instruction counts of the generated row loop (sw_score_asm.inc): packed VALU per row, address increments per 2 rows
+void score_loop_counts(uint32_t* packed_per_row, uint32_t* aux_per_2rows);
 
 
 // ---- device-side top-k selection over the per-slot scores (sw_topk.hip) --------------------------------------

@@ -107,6 +107,7 @@ int ctx_create(int device, Context** out) {
   HIPCK(hipEventCreate(&c->ev2));
   HIPCK(hipEventCreate(&c->ev3));
   if (const char* mb = getenv("SW_HIP_SCRATCH_MB")) c->scratch_budget = (size_t)atoll(mb) << 20;
+  reset_stats(*c);
   *out = c.release();
   return SW_OK;
 }
@@ -126,6 +127,10 @@ int swhip::ctx_get(int device, Context** out) {
   }
   *out = g_ctx[device];
   return SW_OK;
+}
+void swhip::reset_stats(Context& c) {
+  c.stats = sw_kernel_stats{};
+  score_loop_counts(&c.stats.score_packed_per_row, &c.stats.score_aux_per_2rows);
 }
 swhip::CtxLock::CtxLock(int device) {
   rc = ctx_get(device, &c);
@@ -931,6 +936,17 @@ int sw_hip_path_params(int path, uint64_t q_len, uint64_t t_len, uint32_t out[4]
   out[2] = pp.phaseQp;
   out[3] = pp.straight;
   return SW_OK;
+}
+
+uint32_t sw_hip_struct_size(int which) {
+  switch (which) {
+    case 0: return (uint32_t)sizeof(sw_kernel_stats);
+    case 1: return (uint32_t)sizeof(sw_hit);
+    case 2: return (uint32_t)sizeof(sw_alignment_detail);
+    case 3: return (uint32_t)sizeof(sw_work_package);
+    case 4: return (uint32_t)sizeof(sw_work_pair);
+    default: return 0;
+  }
 }
 
 int sw_hip_last_stats(sw_kernel_stats* out) {

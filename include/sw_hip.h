@@ -137,6 +137,15 @@ struct sw_kernel_stats {
   uint64_t exact_cells;
   uint32_t score_launches;
   uint32_t rerun_pairs;     /* pairs re-run by the exact kernel (saturation / quirk / non-ACGT) */
+  /* what the score-kernel launches executed, counted by the library (no pasted constants in bench.py): */
+  uint64_t score_strip_rows;   /* sum over launches of (16-column strips of the database) x (query rows): one
+                                  iteration of the generated row loop each, score_packed_per_row packed VALU
+                                  wave-instructions + score_aux_per_2rows / 2 address increments */
+  uint64_t score_chain_rows;   /* of those, rows also stored to the HBM boundary ring (256 B written once and
+                                  read back once each): units that hand their last column to the next unit */
+  uint32_t score_packed_per_row, score_aux_per_2rows; /* read off the generated loop (sw_score_asm.inc) */
+  uint32_t score_workgroups;   /* persistent workgroups of the last launch */
+  uint32_t pad_;
 };
 int sw_hip_last_stats(struct sw_kernel_stats *out);
 
@@ -158,6 +167,10 @@ int sw_node_last_stats(const sw_node_db *db, int shard, struct sw_kernel_stats *
  * suite check the library's dispatch (rust/src/algorithm/mod.rs:213 and the padded-length quirks) against
  * the oracle's clean model without a GPU. */
 int sw_hip_path_params(int path, uint64_t q_len, uint64_t t_len, uint32_t out[4]);
+/* sizeof() of the additive ABI structs as the library was compiled: 0 = sw_kernel_stats, 1 = sw_hit,
+ * 2 = sw_alignment_detail, 3 = sw_work_package, 4 = sw_work_pair (0 for an unknown index).  Lets a binding written
+ * in another language (ctypes, cgo) assert that its mirror of a struct has not fallen behind the header. */
+uint32_t sw_hip_struct_size(int which);
 /* Builds the score kernel's ticket-ordered unit table for a database whose groups have the given numbers of strips
  * (W strips per unit, S interleaved lanes, R ring slots, max_wg persistent workgroups) and checks the invariants
  * the kernel relies on (coverage, backward dependencies, ring-slot reuse).  Returns the number of units or a
