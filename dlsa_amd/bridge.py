@@ -134,6 +134,9 @@ def lib():
     L.sw_db_search_topk_batch.restype = C.c_int
     L.sw_db_scores.argtypes = [C.c_void_p, C.c_char_p, CScores, C.POINTER(C.c_int32)]
     L.sw_db_scores.restype = C.c_int
+    L.sw_db_scores_noalloc.argtypes = [C.c_void_p, C.c_char_p, CScores, C.POINTER(C.c_int32)]
+    L.sw_db_scores_noalloc.restype = C.c_int
+    L.sw_hip_noalloc_scratch_bytes.restype = C.c_uint64
     L.sw_hits_free.argtypes = [C.POINTER(CHit), C.c_int]
     L.sw_hits_free.restype = None
     L.sw_hip_last_stats.argtypes = [C.POINTER(CStats)]
@@ -311,6 +314,15 @@ class Database:
         rc = lib().sw_db_scores(self._h, _b(query), score.c(), out.ctypes.data_as(C.POINTER(C.c_int32)))
         if rc != 0:
             raise SwHipError(f"sw_db_scores failed ({rc}): {last_error()}")
+        return out
+
+    def scores_noalloc(self, query, score):
+        """sw_db_scores_noalloc: the same scores without any device allocation (fixed scratch, stated limits)."""
+        import numpy as np
+        out = np.zeros(self.n, dtype=np.int32)
+        rc = lib().sw_db_scores_noalloc(self._h, _b(query), score.c(), out.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc != 0:
+            raise SwHipError(f"sw_db_scores_noalloc failed ({rc}): {last_error()}")
         return out
 
     @staticmethod

@@ -393,8 +393,11 @@ bool fast_domain(Scoring sc) {
 
 // Launches the score kernel for one query over the packed part of the database (asynchronous, on the library's
 // stream; ev0/ev1 bracket the kernel).  The per-slot maxima are left in ws.slot_scores.
+// `arena` != nullptr: the allocation-free variant (sw_db_scores_noalloc) -- ws is the fixed workspace carved out
+// of the device's static scratch array, the unit table is built inside the pre-reserved host arena on every call
+// and the number of workgroups is cut down to what the fixed boundary ring can serve.
 int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwords, size_t n_qwords, uint32_t Q,
-                      Scoring sc) {
+                      Scoring sc, HostArena* arena = nullptr) {
   const uint32_t nblk = (Q + kScoreB - 1) / kScoreB;
   const size_t Qpad = (size_t)nblk * kScoreB;
   const uint32_t W = (uint32_t)score_waves_per_group(db->n_elems, c.cus);
@@ -412,7 +415,7 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
   uint32_t n_units;
   uint64_t chained = 0;
   const ScoreUnit* d_units;
-  {
+  if (!arena) {
     const uint32_t ring_min = max_wg * (1 + ahead) + 8;
     const uint64_t ring_fit = 2 * (uint64_t)c.scratch_budget / ((uint64_t)Qpad * 256);
     S = (uint32_t)std::min<uint64_t>(1024, std::max<uint64_t>(8, db->groups.size()));
@@ -435,6 +438,33 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
     n_units = db->n_units;
     chained = db->units_chained;
     d_units = db->d_units;
+  } else {
+    // the fixed ring decides how many workgroups may run: ring_slots = S + nwg * (1 + ahead) + 8 slots of Qpad x 256 B
+    const uint64_t ring_fit = ws.gbound.cap / ((uint64_t)Qpad * 256);
+    S = (uint32_t)std::min<uint64_t>(64, std::max<uint64_t>(2, db->groups.size()));
+    if (ring_fit < (uint64_t)S + 8 + (1 + ahead)) S = 2;
+    if (ring_fit < (uint64_t)S + 8 + (1 + ahead))
+      return fail(SW_E_LIMIT, "sw_db_scores_noalloc: the query is too long for the fixed boundary ring (" +
+                                  std::to_string(ws.gbound.cap >> 20) + " MiB hold " + std::to_string(ring_fit) +
+                                  " columns of this query, " + std::to_string(S + 8 + 1 + ahead) + " are needed)");
+    max_wg = (uint32_t)std::min<uint64_t>(max_wg, (ring_fit - S - 8) / (1 + ahead));
+    ring_slots = S + max_wg * (1 + ahead) + 8;
+    const size_t ng = db->groups.size();
+    const size_t ucap = units_bound(db->n_elems, ng, W, max_wg);
+    ScoreUnit* units = (ScoreUnit*)arena->take(ucap * sizeof(ScoreUnit));
+    UnitLane* lanes = (UnitLane*)arena->take((ng + 1) * sizeof(UnitLane));
+    size_t* active = (size_t*)arena->take(((size_t)S + 1) * sizeof(size_t));
+    uint32_t* slot_reader = (uint32_t*)arena->take((size_t)ring_slots * 4);
+    if (!units || !lanes || !active || !slot_reader)
+      return fail(SW_E_LIMIT, "sw_db_scores_noalloc: the database has too many groups for the pre-reserved host arena");
+    const int64_t n = build_units_raw(db->groups.data(), ng, db->n_elems, W, S, ring_slots, max_wg, units, ucap, lanes,
+                                      active, slot_reader, &chained);
+    if (n < 0) return fail(SW_E_LIMIT, "sw_db_scores_noalloc: unit table overflow");
+    n_units = (uint32_t)n;
+    int rc0;
+    if ((rc0 = ws.units.ensure(std::max<size_t>((size_t)n_units, 1) * sizeof(ScoreUnit)))) return rc0;
+    HIPCK(hipMemcpyAsync(ws.units.p, units, (size_t)n_units * sizeof(ScoreUnit), hipMemcpyHostToDevice, c.stream));
+    d_units = (const ScoreUnit*)ws.units.p;
   }
   const int nwg = (int)std::min<uint32_t>(n_units, max_wg);
   const size_t gb_stride = Qpad * 64;
@@ -776,7 +806,156 @@ sw_db* swhip::db_create_owned(Context* ctx, std::string&& flat, std::vector<uint
 const std::string& swhip::db_flat(const sw_db* db) { return db->flat; }
 const std::vector<uint64_t>& swhip::db_offsets(const sw_db* db) { return db->off; }
 
+// ---- the allocation-free variant of sw_db_scores --------------------------------------------------------------------
+namespace {
+// One pair through the exact kernel, score only, with every buffer taken from the fixed workspace / host arena.
+int exact_one_fixed(Context& c, HostArena& arena, const uint16_t* qsym, uint32_t Q, const unsigned char* tbytes, uint32_t T,
+                    int path, Scoring sc, int32_t* score_out) {
+  Workspace& ws = c.na;
+  const size_t mark = arena.used;
+  struct Restore {
+    HostArena& a;
+    size_t m;
+    ~Restore() { a.used = m; }
+  } restore{arena, mark};
+  const int rpl = 4;
+  const PathParams pp = resolve_path(path, Q, T);
+  const uint32_t maxcol = std::max(pp.Tlim, pp.T0);
+  const uint32_t n_units = std::max<uint32_t>(exact_nstrips(Q, rpl), 1);
+  auto align16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+  const size_t in_units = align16(sizeof(ExactPair)), in_order = in_units + align16((size_t)n_units * 4),
+               in_q = in_order + align16((size_t)n_units * 4), in_t = in_q + align16((size_t)Q * 2 + 2),
+               in_bytes = in_t + align16((size_t)T * 2 + 16);
+  const size_t ctl_words = 64 + 1, z_bnd = align16(ctl_words * 4),
+               z_bytes = z_bnd + align16(std::max<size_t>((size_t)n_units * (maxcol + 2) * 4, 16));
+  int rc;
+  if ((rc = ws.xin.ensure(in_bytes))) return rc;
+  if ((rc = ws.xzero.ensure(z_bytes))) return rc;
+  if ((rc = ws.xout.ensure(sizeof(ExactOut)))) return rc;
+  if ((rc = ws.xrecs.ensure((size_t)n_units * sizeof(ExactRec)))) return rc;
+  unsigned char* h = (unsigned char*)arena.take(in_bytes);
+  ExactOut* ho = (ExactOut*)arena.take(sizeof(ExactOut));
+  if (!h || !ho) return fail(SW_E_LIMIT, "sw_db_scores_noalloc: a target that needs the int32 re-run is too long for the host arena");
+  unsigned char* const d_in = (unsigned char*)ws.xin.p;
+  unsigned char* const d_zero = (unsigned char*)ws.xzero.p;
+  ExactPair e{};
+  e.q = (const uint16_t*)(d_in + in_q);
+  e.t = (const uint16_t*)(d_in + in_t);
+  e.Q = Q;
+  e.T = T;
+  e.Tlim = pp.Tlim;
+  e.T0 = pp.T0;
+  e.phaseQp = pp.phaseQp;
+  e.straight = pp.straight;
+  e.bnd = (int32_t*)(d_zero + z_bnd);
+  e.bnd_pitch = maxcol + 2;
+  e.dirs = nullptr;
+  e.nkb = exact_nsteps(maxcol) / 16;
+  e.ops = nullptr;
+  e.first_unit = 0;
+  e.n_units = n_units;
+  memcpy(h, &e, sizeof(e));
+  uint32_t* up = (uint32_t*)(h + in_units);
+  uint32_t* uo = (uint32_t*)(h + in_order);
+  for (uint32_t u = 0; u < n_units; u++) up[u] = 0, uo[u] = u;
+  memcpy(h + in_q, qsym, (size_t)Q * 2);
+  uint16_t* ts = (uint16_t*)(h + in_t);
+  for (uint32_t i = 0; i < T; i++) ts[i] = tbytes[i];
+  HIPCK(hipMemcpyAsync(d_in, h, in_bytes, hipMemcpyHostToDevice, c.stream));
+  HIPCK(hipMemsetAsync(d_zero, 0, z_bytes, c.stream));
+  ExactWork w{};
+  w.pairs = (const ExactPair*)d_in;
+  w.outs = (ExactOut*)ws.xout.p;
+  w.unit_pair = (const uint32_t*)(d_in + in_units);
+  w.unit_order = (const uint32_t*)(d_in + in_order);
+  w.n_units = n_units;
+  w.n_pairs = 1;
+  w.rpl = rpl;
+  w.ticket = (uint32_t*)d_zero;
+  w.err = (uint32_t*)d_zero + 32;
+  w.pair_done = (uint32_t*)d_zero + 64;
+  w.recs = (ExactRec*)ws.xrecs.p;
+  HIPCK(launch_exact(w, sc, c.stream));
+  HIPCK(hipMemcpyAsync(ho, ws.xout.p, sizeof(ExactOut), hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipStreamSynchronize(c.stream));
+  if (ho->nops == 0xffffffffu) return fail(SW_E_HIP, "exact kernel: strip pipeline wait timed out");
+  *score_out = ho->score;
+  c.stats.exact_cells += (uint64_t)Q * T;
+  c.stats.rerun_pairs += 1;
+  return SW_OK;
+}
+
+int db_scores_noalloc(sw_db* db, const char* query, AlignmentScores as, int32_t* scores_out) {
+  if (!db || !query || !scores_out) return fail(SW_E_ARG, "null argument");
+  const Scoring sc = to_scoring(as);
+  if (!fast_domain(sc))
+    return fail(SW_E_DOMAIN, "sw_db_scores_noalloc: scoring outside match > 0, mismatch < 0, gap < 0; use sw_db_scores");
+  for (uint32_t ti : db->generic)
+    if (db->off[ti + 1] > db->off[ti])
+      return fail(SW_E_DOMAIN, "sw_db_scores_noalloc: the database holds a sequence with symbols outside ACGT (index " +
+                                   std::to_string(ti) + "); use sw_db_scores");
+  const size_t Qlen = strlen(query);
+  for (size_t i = 0; i < Qlen; i++)
+    if (nt_code((unsigned char)query[i]) < 0)
+      return fail(SW_E_DOMAIN, "sw_db_scores_noalloc: the query holds symbols outside ACGT; use sw_db_scores");
+  if (Qlen > 0x10000) return fail(SW_E_LIMIT, "sw_db_scores_noalloc: query longer than 65536 residues");
+  for (uint64_t i = 0; i < db->n; i++) scores_out[i] = 0;
+  if (Qlen == 0 || db->groups.empty()) return SW_OK;
+  const uint32_t Q = (uint32_t)Qlen;
+  CtxLock L(db->ctx);
+  if (L.rc) return L.rc;
+  Context& c = *L.c;
+  HostArena& arena = c.na_host;
+  arena.reset();
+  reset_stats(c);
+  const size_t n_qwords = (Q + kScoreB - 1) / kScoreB + 1;
+  uint32_t* qwords = (uint32_t*)arena.take(n_qwords * 4);
+  uint16_t* qsym = (uint16_t*)arena.take((size_t)Q * 2);
+  const size_t n_slots = db->slot_target.size();
+  int32_t* slot = (int32_t*)arena.take(n_slots * 4);
+  if (!qwords || !qsym || !slot)
+    return fail(SW_E_LIMIT, "sw_db_scores_noalloc: the database is too large for the pre-reserved host arena (" +
+                                std::to_string(n_slots) + " slots)");
+  memset(qwords, 0, n_qwords * 4);
+  for (uint32_t i = 0; i < Q; i++) {
+    qwords[i / kScoreB] |= (uint32_t)nt_code((unsigned char)query[i]) << (2 * (i % kScoreB));
+    qsym[i] = (unsigned char)query[i];
+  }
+  StreamDrain drain(c.stream);
+  int rc = score_pass_locked(c, c.na, db, qwords, n_qwords, Q, sc, &arena);
+  if (rc) return rc;
+  uint32_t* kerr = (uint32_t*)arena.take(4);
+  if (!kerr) return fail(SW_E_LIMIT, "sw_db_scores_noalloc: host arena exhausted");
+  *kerr = 0;
+  HIPCK(hipMemcpyAsync(slot, c.na.slot_scores.p, n_slots * 4, hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipMemcpyAsync(kerr, (uint32_t*)c.na.ticket.p + 32, 4, hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipStreamSynchronize(c.stream));
+  if ((rc = score_pass_finish_locked(c, db, Q, *kerr))) return rc;
+  const uint32_t Qp = roundup64(Q);
+  for (size_t k = 0; k < n_slots; k++) {
+    const uint32_t ti = db->slot_target[k];
+    if (ti == UINT32_MAX) continue;
+    const uint32_t T = (uint32_t)(db->off[ti + 1] - db->off[ti]);
+    if (!needs_exact(T, slot[k], Q, Qp, sc)) {
+      scores_out[ti] = slot[k];
+      continue;
+    }
+    // saturated / quirk lengths: the int32 exact kernel, one pair per submission, same fixed scratch
+    int32_t v = 0;
+    rc = exact_one_fixed(c, arena, qsym, Q, (const unsigned char*)db->flat.data() + db->off[ti], T, db_pair_path(Q, T, sc), sc, &v);
+    if (rc) return rc;
+    scores_out[ti] = v;
+  }
+  return SW_OK;
+}
+}  // namespace
+
 extern "C" {
+
+int sw_db_scores_noalloc(sw_db* db, const char* query, AlignmentScores as, int32_t* scores_out) {
+  return swhip::guarded<int>(SW_E_NOMEM, [&] { return db_scores_noalloc(db, query, as, scores_out); });
+}
+uint64_t sw_hip_noalloc_scratch_bytes(void) { return noalloc_scratch_bytes(); }
 
 sw_db* sw_db_create(const char* flat, const uint64_t* offsets, uint64_t n) {
   return swhip::guarded<sw_db*>(nullptr, [&]() -> sw_db* {

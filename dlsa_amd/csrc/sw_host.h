@@ -67,6 +67,20 @@ struct Workspace {
 
 constexpr int kMaxDevices = 64;
 
+// A block of plain host memory reserved when a context is set up; the allocation-free entry point carves its
+// temporaries out of it with a bump pointer (reset at the start of every call, under the context's lock).
+struct HostArena {
+  unsigned char* base = nullptr;
+  size_t cap = 0, used = 0;
+  void reset() { used = 0; }
+  void* take(size_t bytes) {
+    const size_t at = (used + 63) & ~(size_t)63;
+    if (at + bytes > cap || at + bytes < at) return nullptr;
+    used = at + bytes;
+    return base + at;
+  }
+};
+
 struct Context {
   std::mutex mu;  // one GPU submission at a time per device; the ABI is entered from many threads
   int device = 0;
@@ -74,6 +88,11 @@ struct Context {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   Workspace ws;
+  // the allocation-free entry point (sw_db_scores_noalloc): windows of this device's copy of the static scratch
+  // array (sw_lib.cpp) and a host arena, both bound once when the context is created
+  Workspace na;
+  HostArena na_host;
+  void* na_scratch = nullptr;  // device address of the scratch array on THIS device (hipGetSymbolAddress)
   sw_kernel_stats stats{};
   size_t scratch_budget = (size_t)8 << 30;
 };
@@ -82,6 +101,7 @@ struct Context {
 // selects and which is 0 otherwise).  On failure *out is null and the error is recorded.
 int ctx_get(int device, Context** out);
 void reset_stats(Context& c);
+size_t noalloc_scratch_bytes();
 // Locks a context for one submission and makes its device current for the calling thread (HIP's current device
 // is per thread; the ABI is entered from many threads).
 struct CtxLock {

@@ -81,6 +81,21 @@ void HostBuf::release() {
 // process's DEFAULT device (sw_hip_init, else 0: one process per GPU, as bench.py under torchrun); the node API
 // (sw_node.cpp) reaches every device of the machine from one process, each through its own context, lock, stream
 // and scratch, so searches on different GPUs never serialise on each other.
+// ---- the scratch of the allocation-free entry point ---------------------------------------------------------
+// sw_db_scores_noalloc (include/sw_hip.h) may not call hipMalloc: everything its kernels need beyond inputs and
+// outputs lives in this file-scope device array.  Every GPU the library runs on holds its own copy at its own
+// address until the process ends; `scratch` itself is only a host-side stand-in for the symbol, so the device
+// address is looked up once per device when its context is created (ctx_create, that device current) and only that
+// pointer is ever used -- as kernel argument, for hipMemsetAsync and for copies.
+constexpr size_t kNaQwords = (size_t)64 << 10, kNaTicket = (size_t)4 << 10, kNaProg = (size_t)1 << 20,
+                 kNaUnits = (size_t)2 << 20, kNaSlotScores = (size_t)8 << 20, kNaXin = (size_t)4 << 20,
+                 kNaXzero = (size_t)6 << 20, kNaXout = (size_t)1 << 20, kNaXrecs = (size_t)256 << 10,
+                 kNaRing = (size_t)72 << 20;
+constexpr size_t kNaScratchBytes =
+    kNaQwords + kNaTicket + kNaProg + kNaUnits + kNaSlotScores + kNaXin + kNaXzero + kNaXout + kNaXrecs + kNaRing;
+static __device__ __align__(256) unsigned char scratch[kNaScratchBytes];
+constexpr size_t kNaHostBytes = (size_t)24 << 20;  // host arena: slot scores, unit table, symbols, staging
+
 namespace {
 std::mutex g_ctx_mu;  // creation of contexts and the default device
 Context* g_ctx[kMaxDevices] = {};
@@ -107,6 +122,36 @@ int ctx_create(int device, Context** out) {
   HIPCK(hipEventCreate(&c->ev2));
   HIPCK(hipEventCreate(&c->ev3));
   if (const char* mb = getenv("SW_HIP_SCRATCH_MB")) c->scratch_budget = (size_t)atoll(mb) << 20;
+  // this device's copy of the scratch array (the device is current: hipSetDevice above)
+  void* ptr = nullptr;
+  HIPCK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+  if (!ptr) return fail(SW_E_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+  c->na_scratch = ptr;
+  {
+    unsigned char* at = (unsigned char*)ptr;
+    auto window = [&](DevBuf& b, size_t bytes) {
+      b.bind_fixed(at, bytes);
+      at += bytes;
+    };
+    window(c->na.qwords, kNaQwords);
+    window(c->na.ticket, kNaTicket);
+    window(c->na.prog, kNaProg);
+    window(c->na.units, kNaUnits);
+    window(c->na.slot_scores, kNaSlotScores);
+    window(c->na.xin, kNaXin);
+    window(c->na.xzero, kNaXzero);
+    window(c->na.xout, kNaXout);
+    window(c->na.xrecs, kNaXrecs);
+    window(c->na.gbound, kNaRing);
+    // (the traceback and selection buffers stay empty windows: the entry point uses neither)
+    for (DevBuf* b : {&c->na.dirs, &c->na.sel_hist, &c->na.sel_ctr, &c->na.sel_rerun, &c->na.sel_cand, &c->na.sel_tie})
+      b->bind_fixed(nullptr, 0);
+  }
+  c->na_host.base = (unsigned char*)malloc(kNaHostBytes);
+  if (!c->na_host.base) return fail(SW_E_NOMEM, "out of host memory");
+  c->na_host.cap = kNaHostBytes;
+  c->na.h_in.bind_fixed(nullptr, 0);
+  c->na.h_out.bind_fixed(nullptr, 0);
   reset_stats(*c);
   *out = c.release();
   return SW_OK;
@@ -132,6 +177,7 @@ void swhip::reset_stats(Context& c) {
   c.stats = sw_kernel_stats{};
   score_loop_counts(&c.stats.score_packed_per_row, &c.stats.score_aux_per_2rows);
 }
+size_t swhip::noalloc_scratch_bytes() { return kNaScratchBytes; }
 swhip::CtxLock::CtxLock(int device) {
   rc = ctx_get(device, &c);
   if (rc) return;

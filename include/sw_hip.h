@@ -99,6 +99,29 @@ int sw_db_search_topk_batch(sw_db *db, const char *const *queries, size_t n_quer
 int sw_db_scores(sw_db *db, const char *query, struct AlignmentScores scores, int32_t *scores_out);
 void sw_hits_free(struct sw_hit *hits, int n_hits);
 
+/* ---- the one entry point that allocates nothing --------------------------------------------------------------
+ * No counterpart in the reference.  For callers that cannot call hipMalloc: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid allocation.  sw_db_scores for the same arguments, with the same result,
+ * but every byte its kernels need beyond the inputs (the resident database, the query) and the output lives in a
+ * file-scope device array of sw_hip_noalloc_scratch_bytes() bytes (96 MiB; every GPU the library runs on holds
+ * its own copy until the process ends) and in a host arena reserved when the device's context is set up
+ * (sw_hip_init / first use of the device).  The call performs no hipMalloc, hipFree, hipHostMalloc or any other
+ * allocating routine, on the device or on the host.  Limits, each an error (SW_E_LIMIT / SW_E_DOMAIN with a
+ * message), never a fallback to allocation:
+ *   - scoring with match > 0, mismatch < 0, gap < 0; query and every non-empty database sequence over ACGT only
+ *     (the packed kernel's domain; anything else: use sw_db_scores);
+ *   - query <= 65536 residues, and short enough that the fixed boundary ring (72 MiB) holds a few columns of it:
+ *     about 24 500 residues; fewer workgroups run the longer the query is (256 up to ~200 residues, ~110 at
+ *     1 kb, 9 at 10 kb), so long queries are slower here than through sw_db_scores;
+ *   - database <= 2 097 152 lane slots (targets rounded up to groups of 128) and <= 131 072 work units;
+ *   - targets that need the int32 re-run (int16 saturation, padded-length quirks) are re-scored one pair per
+ *     submission inside the same scratch: exact, but slow when there are many.
+ * All calls on one GPU share that GPU's array; the library serialises them with the device's lock, callers that
+ * bypass the library's lock (there are none in this ABI) would race.  The array keeps the last call's contents;
+ * what must start at zero is cleared by every call. */
+int sw_db_scores_noalloc(sw_db *db, const char *query, struct AlignmentScores scores, int32_t *scores_out);
+uint64_t sw_hip_noalloc_scratch_bytes(void);
+
 /* ---- one worker process, several GPUs -----------------------------------------------------
  * The reference spreads a job over worker PROCESSES by (query, target) pair
  * (master/work_package/_scheduler/proportional_work_scheduler.py:30-55) and sorts every pair's score client-side
