@@ -121,6 +121,14 @@ def lib():
     L.sw_db_create.restype = C.c_void_p
     L.sw_db_load_fasta.argtypes = [C.c_char_p]
     L.sw_db_load_fasta.restype = C.c_void_p
+    L.sw_db_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.sw_db_save.restype = C.c_int
+    L.sw_db_open.argtypes = [C.c_char_p]
+    L.sw_db_open.restype = C.c_void_p
+    L.sw_node_db_save.argtypes = [C.c_void_p, C.c_char_p]
+    L.sw_node_db_save.restype = C.c_int
+    L.sw_node_db_open.argtypes = [C.c_void_p, C.c_char_p]
+    L.sw_node_db_open.restype = C.c_void_p
     L.sw_db_free.argtypes = [C.c_void_p]
     L.sw_db_free.restype = None
     L.sw_db_size.argtypes = [C.c_void_p]
@@ -273,8 +281,14 @@ def align_batch(queries, targets, score, path=0):
 class Database:
     """A resident target database (sw_db_*)."""
 
-    def __init__(self, seqs=None, flat=None, offsets=None, fasta=None):
+    def __init__(self, seqs=None, flat=None, offsets=None, fasta=None, path=None):
         L = lib()
+        if path is not None:  # a file written by save()
+            self._h = L.sw_db_open(_b(path))
+            if not self._h:
+                raise SwHipError(f"sw_db_open failed: {last_error()}")
+            self.n = int(L.sw_db_size(self._h))
+            return
         if fasta is not None:  # a Fasta object (dlsa_amd.worker)
             self._h = L.sw_db_from_fasta(fasta._h)
             n = len(fasta)
@@ -296,6 +310,11 @@ class Database:
         if not self._h:
             raise SwHipError(f"sw_db_create failed: {last_error()}")
         self.n = n
+
+    def save(self, path):
+        rc = lib().sw_db_save(self._h, _b(path))
+        if rc != 0:
+            raise SwHipError(f"sw_db_save failed ({rc}): {last_error()}")
 
     def close(self):
         if self._h:
@@ -441,9 +460,16 @@ class Node:
 class NodeDatabase:
     """sw_node_db: one database sharded by target over the GPUs of a Node."""
 
-    def __init__(self, node, seqs=None, flat=None, offsets=None):
+    def __init__(self, node, seqs=None, flat=None, offsets=None, path=None):
         import numpy as np
         L = lib()
+        self._node = node
+        if path is not None:  # a directory written by save()
+            self._h = L.sw_node_db_open(node._h, _b(path))
+            if not self._h:
+                raise SwHipError(f"sw_node_db_open failed: {last_error()}")
+            self.n = int(L.sw_node_db_size(self._h))
+            return
         if seqs is not None:
             bs = [_b(s) for s in seqs]
             flat = b"".join(bs)
@@ -456,6 +482,11 @@ class NodeDatabase:
         self._h = L.sw_node_db_create(node._h, buf, offsets.ctypes.data_as(C.POINTER(C.c_uint64)), self.n)
         if not self._h:
             raise SwHipError(f"sw_node_db_create failed: {last_error()}")
+
+    def save(self, path):
+        rc = lib().sw_node_db_save(self._h, _b(path))
+        if rc != 0:
+            raise SwHipError(f"sw_node_db_save failed ({rc}): {last_error()}")
 
     def shard_info(self):
         L = lib()

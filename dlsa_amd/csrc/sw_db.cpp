@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <array>
 #include <atomic>
+#include <cerrno>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -67,6 +68,28 @@ void db_release(sw_db* db) {
 struct DbDeleter {
   void operator()(sw_db* d) const { db_release(d); }
 };
+// The packed part of a database goes to the device (caller holds the context's lock, its device is current).
+bool db_upload(sw_db* db, const std::vector<uint32_t>& words, const std::vector<uint32_t>& lens,
+               const std::vector<uint32_t>& elem_group) {
+  const size_t ngroups = db->groups.size();
+  if (!ngroups) return true;
+  if (hipMalloc(&db->d_words, words.size() * 4) != hipSuccess || hipMalloc(&db->d_lens, lens.size() * 4) != hipSuccess ||
+      hipMalloc(&db->d_slot_target, lens.size() * 4) != hipSuccess ||
+      hipMalloc(&db->d_groups, ngroups * sizeof(ScoreGroup)) != hipSuccess ||
+      hipMalloc(&db->d_elem_group, elem_group.size() * 4) != hipSuccess) {
+    fail(SW_E_NOMEM, "hipMalloc failed for the database");
+    return false;
+  }
+  if (hipMemcpy(db->d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(db->d_lens, lens.data(), lens.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(db->d_slot_target, db->slot_target.data(), lens.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(db->d_groups, db->groups.data(), ngroups * sizeof(ScoreGroup), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(db->d_elem_group, elem_group.data(), elem_group.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    fail(SW_E_HIP, "hipMemcpy failed for the database");
+    return false;
+  }
+  return true;
+}
 // Caller holds the context's lock (its device is current).
 sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
   std::unique_ptr<sw_db, DbDeleter> holder(new sw_db);  // an exception below must not leak the device arrays
@@ -184,23 +207,189 @@ sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
       }
     }
   });
-  if (ngroups) {
-    if (hipMalloc(&db->d_words, words.size() * 4) != hipSuccess || hipMalloc(&db->d_lens, lens.size() * 4) != hipSuccess ||
-        hipMalloc(&db->d_slot_target, lens.size() * 4) != hipSuccess ||
-        hipMalloc(&db->d_groups, ngroups * sizeof(ScoreGroup)) != hipSuccess ||
-        hipMalloc(&db->d_elem_group, elem_group.size() * 4) != hipSuccess) {
-      fail(SW_E_NOMEM, "hipMalloc failed for the database");
-      return nullptr;
-    }
-    if (hipMemcpy(db->d_words, words.data(), words.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(db->d_lens, lens.data(), lens.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(db->d_slot_target, db->slot_target.data(), lens.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(db->d_groups, db->groups.data(), ngroups * sizeof(ScoreGroup), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(db->d_elem_group, elem_group.data(), elem_group.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-      fail(SW_E_HIP, "hipMemcpy failed for the database");
-      return nullptr;
-    }
+  if (!db_upload(db, words, lens, elem_group)) return nullptr;
+  return holder.release();
+}
+
+// ---- the packed database on disk ----------------------------------------------------------
+// One file per database (per shard for a node database): what sw_db_create computes from raw sequences --
+// validation, the length sort, the groups of 128 lanes and the 2-bit strip stream -- stored as it goes to the
+// device, so that opening it is a read plus an upload.  Sequences outside ACGT (the escape list) are stored as
+// bytes; the original bytes of the packed sequences are not stored, they are unpacked from the strip stream on
+// open (they are needed on the host for end cells and tracebacks of reported hits).  Little-endian, 8-byte
+// aligned sections in this order: lengths in database order (u32 x n), slot -> database index (u32 x 128 x groups),
+// group table, strip stream (u32 x 128 x strips), escape list (u32 x n_generic), escape bytes.
+struct DbFileHeader {
+  char magic[8];  // "SWHIPDB" + version byte
+  uint32_t header_bytes, group_bytes;
+  uint64_t n, residues, packed_residues, n_groups, n_elems, n_generic, generic_bytes;
+  uint32_t max_len, reserved;
+};
+const char kDbMagic[8] = {'S', 'W', 'H', 'I', 'P', 'D', 'B', 1};
+
+struct FileCloser {
+  FILE* f;
+  ~FileCloser() {
+    if (f) fclose(f);
   }
+};
+bool write_section(FILE* f, const void* p, size_t bytes) {
+  static const char zeros[8] = {0};
+  if (bytes && fwrite(p, 1, bytes, f) != bytes) return false;
+  const size_t pad = (8 - bytes % 8) % 8;
+  return !pad || fwrite(zeros, 1, pad, f) == pad;
+}
+bool read_section(FILE* f, void* p, size_t bytes) {
+  char pad[8];
+  if (bytes && fread(p, 1, bytes, f) != bytes) return false;
+  const size_t n = (8 - bytes % 8) % 8;
+  return !n || fread(pad, 1, n, f) == n;
+}
+
+// Caller holds the context's lock.
+int db_save_locked(const sw_db* db, const char* path) {
+  const size_t ngroups = db->groups.size();
+  std::vector<uint32_t> words((size_t)db->n_elems * kGroupTargets);
+  if (!words.empty()) HIPCK(hipMemcpy(words.data(), db->d_words, words.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<uint32_t> lens(db->n);
+  for (uint64_t i = 0; i < db->n; i++) lens[i] = (uint32_t)(db->off[i + 1] - db->off[i]);
+  std::string gbytes;
+  for (uint32_t ti : db->generic) gbytes.append(db->flat, db->off[ti], db->off[ti + 1] - db->off[ti]);
+  DbFileHeader h{};
+  memcpy(h.magic, kDbMagic, 8);
+  h.header_bytes = sizeof(DbFileHeader);
+  h.group_bytes = sizeof(ScoreGroup);
+  h.n = db->n;
+  h.residues = db->residues;
+  h.packed_residues = db->packed_residues;
+  h.n_groups = ngroups;
+  h.n_elems = db->n_elems;
+  h.n_generic = db->generic.size();
+  h.generic_bytes = gbytes.size();
+  h.max_len = db->max_len;
+  FILE* fp = fopen(path, "wb");
+  if (!fp) return fail(SW_E_ARG, std::string("sw_db_save: cannot open ") + path + ": " + strerror(errno));
+  FileCloser closer{fp};
+  bool ok = write_section(fp, &h, sizeof(h)) && write_section(fp, lens.data(), lens.size() * 4) &&
+            write_section(fp, db->slot_target.data(), db->slot_target.size() * 4) &&
+            write_section(fp, db->groups.data(), ngroups * sizeof(ScoreGroup)) &&
+            write_section(fp, words.data(), words.size() * 4) &&
+            write_section(fp, db->generic.data(), db->generic.size() * 4) && write_section(fp, gbytes.data(), gbytes.size());
+  closer.f = nullptr;
+  if (fclose(fp) != 0) ok = false;
+  if (!ok) return fail(SW_E_ARG, std::string("sw_db_save: write error on ") + path);
+  return SW_OK;
+}
+
+// Caller holds the context's lock (its device is current).
+sw_db* db_open_locked(Context* ctx, const char* path) {
+  FILE* fp = fopen(path, "rb");
+  if (!fp) {
+    fail(SW_E_ARG, std::string("sw_db_open: cannot open ") + path + ": " + strerror(errno));
+    return nullptr;
+  }
+  FileCloser closer{fp};
+  auto bad = [&](const char* what) -> sw_db* {
+    fail(SW_E_ARG, std::string("sw_db_open: ") + path + ": " + what);
+    return nullptr;
+  };
+  DbFileHeader h{};
+  if (!read_section(fp, &h, sizeof(h))) return bad("truncated header");
+  if (memcmp(h.magic, kDbMagic, 8) != 0 || h.header_bytes != sizeof(DbFileHeader) || h.group_bytes != sizeof(ScoreGroup))
+    return bad("not a libsw_hip database file of this version");
+  if (h.n >= 0xffffffffull || h.n_groups > h.n + 1 || h.n_elems > 0xfff00000ull || h.n_generic > h.n ||
+      h.residues > ((uint64_t)1 << 46) || h.generic_bytes > h.residues || h.packed_residues > h.residues)
+    return bad("implausible header");
+  std::unique_ptr<sw_db, DbDeleter> holder(new sw_db);
+  sw_db* db = holder.get();
+  db->ctx = ctx;
+  db->n = h.n;
+  db->residues = h.residues;
+  db->packed_residues = h.packed_residues;
+  db->n_elems = (uint32_t)h.n_elems;
+  db->max_len = h.max_len;
+  const size_t n_slots = (size_t)h.n_groups * kGroupTargets;
+  std::vector<uint32_t> lens_by_target(h.n), words((size_t)h.n_elems * kGroupTargets);
+  db->slot_target.resize(n_slots);
+  db->groups.resize(h.n_groups);
+  db->generic.resize(h.n_generic);
+  std::string gbytes(h.generic_bytes, '\0');
+  if (!read_section(fp, lens_by_target.data(), lens_by_target.size() * 4) ||
+      !read_section(fp, db->slot_target.data(), n_slots * 4) ||
+      !read_section(fp, db->groups.data(), db->groups.size() * sizeof(ScoreGroup)) ||
+      !read_section(fp, words.data(), words.size() * 4) || !read_section(fp, db->generic.data(), db->generic.size() * 4) ||
+      !read_section(fp, &gbytes[0], gbytes.size()))
+    return bad("truncated file");
+  // the kernels index with these tables: check every one against the others before anything reaches the device
+  db->off.assign(h.n + 1, 0);
+  for (uint64_t i = 0; i < h.n; i++) {
+    if (lens_by_target[i] >= 0x7fffff00u || lens_by_target[i] > h.max_len) return bad("sequence length out of range");
+    db->off[i + 1] = db->off[i] + lens_by_target[i];
+  }
+  if (db->off[h.n] != h.residues) return bad("lengths do not add up to the residue count");
+  uint64_t strips = 0;
+  for (size_t g = 0; g < db->groups.size(); g++) {
+    const ScoreGroup& G = db->groups[g];
+    if (G.strip_base != strips || G.first_slot != g * kGroupTargets || G.nstrips == 0) return bad("inconsistent group table");
+    strips += G.nstrips;
+  }
+  if (strips != h.n_elems) return bad("group table and strip stream disagree");
+  db->packed_ok.assign(h.n, 0);
+  std::vector<uint32_t> lens(n_slots, 0);
+  uint64_t packed_res = 0;
+  for (size_t k = 0; k < n_slots; k++) {
+    const uint32_t ti = db->slot_target[k];
+    if (ti == UINT32_MAX) continue;
+    if (ti >= h.n || db->packed_ok[ti] || lens_by_target[ti] == 0) return bad("slot table names a bad sequence");
+    if ((lens_by_target[ti] + kScoreR - 1) / kScoreR > db->groups[k / kGroupTargets].nstrips) return bad("sequence longer than its group");
+    db->packed_ok[ti] = 1;
+    lens[k] = lens_by_target[ti];
+    packed_res += lens[k];
+  }
+  if (packed_res != h.packed_residues) return bad("packed residue count mismatch");
+  uint64_t gb = 0;
+  for (uint32_t ti : db->generic) {
+    if (ti >= h.n || db->packed_ok[ti] == 1 || db->packed_ok[ti] == 2) return bad("escape list names a bad sequence");
+    db->packed_ok[ti] = 2;
+    gb += lens_by_target[ti];
+  }
+  if (gb != h.generic_bytes || packed_res + gb != h.residues) return bad("escape bytes mismatch");
+  for (uint64_t i = 0; i < h.n; i++)
+    if (!db->packed_ok[i]) return bad("a sequence is neither packed nor on the escape list");
+  // rebuild the host copy of the sequences: escape bytes as stored, packed ones out of the strip stream
+  db->flat.assign(h.residues, '\0');
+  gb = 0;
+  for (uint32_t ti : db->generic) {
+    if (memchr(gbytes.data() + gb, 0, lens_by_target[ti])) return bad("NUL byte inside a sequence");
+    Decoded d;
+    if (!decode(gbytes.data() + gb, lens_by_target[ti], d)) return bad("escape sequence is not valid UTF-8");
+    memcpy(&db->flat[db->off[ti]], gbytes.data() + gb, lens_by_target[ti]);
+    db->packed_ok[ti] = 0;
+    gb += lens_by_target[ti];
+  }
+  std::vector<uint32_t> elem_group(std::max<size_t>(h.n_elems, 1), 0);
+  static const char kNt[4] = {'A', 'C', 'G', 'T'};
+  parallel_ranges(db->groups.size(), db->groups.size() >= 32 ? (size_t)h.residues + ((size_t)1 << 20) : 0, [&](size_t glo, size_t ghi) {
+    for (size_t g = glo; g < ghi; g++) {
+      const ScoreGroup& G = db->groups[g];
+      for (uint32_t st = 0; st < G.nstrips; st++) elem_group[G.strip_base + st] = (uint32_t)g;
+      for (int sl = 0; sl < kGroupTargets; sl++) {
+        const size_t k = g * kGroupTargets + sl;
+        const uint32_t ti = db->slot_target[k];
+        if (ti == UINT32_MAX) continue;
+        char* dst = &db->flat[db->off[ti]];
+        const uint32_t len = lens[k];
+        const uint32_t* src = words.data() + (size_t)G.strip_base * kGroupTargets + (size_t)(sl / 64) * 64 + (sl % 64);
+        for (uint32_t col = 0; col < len; col += kScoreR, src += kGroupTargets) {
+          uint32_t w = *src;
+          const uint32_t nr = std::min<uint32_t>(kScoreR, len - col);
+          for (uint32_t r = 0; r < nr; r++, w >>= 2) dst[col + r] = kNt[w & 3];
+        }
+      }
+    }
+  });
+  if (words.empty()) words.push_back(0);
+  if (!db_upload(db, words, lens, elem_group)) return nullptr;
   return holder.release();
 }
 
@@ -803,6 +992,15 @@ sw_db* swhip::db_create_owned(Context* ctx, std::string&& flat, std::vector<uint
   if (L.rc) return nullptr;
   return db_build(L.c, std::move(flat), std::move(off));
 }
+sw_db* swhip::db_open_on(Context* ctx, const char* path) {
+  if (!path) {
+    fail(SW_E_ARG, "null argument");
+    return nullptr;
+  }
+  CtxLock L(ctx);
+  if (L.rc) return nullptr;
+  return db_open_locked(L.c, path);
+}
 const std::string& swhip::db_flat(const sw_db* db) { return db->flat; }
 const std::vector<uint64_t>& swhip::db_offsets(const sw_db* db) { return db->off; }
 
@@ -977,6 +1175,22 @@ sw_db* sw_db_load_fasta(const char* path) {
   sw_db* db = sw_db_from_fasta(f);
   sw_fasta_free(f);
   return db;
+}
+
+int sw_db_save(sw_db* db, const char* path) {
+  return swhip::guarded<int>(SW_E_NOMEM, [&]() -> int {
+    if (!db || !path) return fail(SW_E_ARG, "null argument");
+    CtxLock L(db->ctx);
+    if (L.rc) return L.rc;
+    return db_save_locked(db, path);
+  });
+}
+sw_db* sw_db_open(const char* path) {
+  return swhip::guarded<sw_db*>(nullptr, [&]() -> sw_db* {
+    Context* c = nullptr;
+    if (ctx_get(-1, &c)) return nullptr;
+    return db_open_on(c, path);
+  });
 }
 
 void sw_db_free(sw_db* db) {

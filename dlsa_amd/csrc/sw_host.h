@@ -225,6 +225,7 @@ int db_align_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring sc, con
 Context* db_context(sw_db* db);
 sw_db* db_create_on(Context* ctx, const char* flat, const uint64_t* offsets, uint64_t n);
 sw_db* db_create_owned(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off);
+sw_db* db_open_on(Context* ctx, const char* path);  // a file written by sw_db_save
 const std::string& db_flat(const sw_db* db);
 const std::vector<uint64_t>& db_offsets(const sw_db* db);
 double benchmark_cups_on(Context* ctx);  // cells per second of the batch path on one device

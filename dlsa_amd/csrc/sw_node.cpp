@@ -8,8 +8,11 @@
 // split is by TARGET, balanced by residues, inside one process; each shard is an ordinary resident database
 // (sw_db.cpp) on its own device context with its own host thread, stream and scratch, so the per-GPU path is
 // exactly the single-GPU path and nothing is shared on the data path.
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -32,6 +35,8 @@ struct sw_node_db {
 };
 
 namespace {
+
+constexpr uint64_t kNodeMagic = 0x0145444f4e505753ull;  // "SWPNODE" + version 1
 
 // ---- the sharder ---------------------------------------------------------------------------------------------
 // Targets are sorted by length (descending, stable on the index) -- the order in which a database packs them into
@@ -244,6 +249,88 @@ sw_node_db* sw_node_db_create(sw_node* node, const char* flat, const uint64_t* o
       }
       ndb->shards[s] = db_create_owned(ndb->ctx[s], std::move(f), std::move(off));
       return ndb->shards[s] ? SW_OK : SW_E_HIP;
+    });
+    if (rc) return nullptr;
+    return ndb.release();
+  });
+}
+int sw_node_db_save(sw_node_db* ndb, const char* dir) {
+  return guarded<int>(SW_E_NOMEM, [&]() -> int {
+    if (!ndb || !dir) return fail(SW_E_ARG, "null argument");
+    if (mkdir(dir, 0777) != 0 && errno != EEXIST)
+      return fail(SW_E_ARG, std::string("sw_node_db_save: cannot create ") + dir + ": " + strerror(errno));
+    const std::string base = std::string(dir) + "/";
+    const size_t S = ndb->shards.size();
+    int rc = on_every_shard(S, [&](size_t s) {
+      char name[32];
+      snprintf(name, sizeof name, "shard-%03zu.swdb", s);
+      return sw_db_save(ndb->shards[s], (base + name).c_str());
+    });
+    if (rc) return rc;
+    FILE* fp = fopen((base + "node.swnode").c_str(), "wb");
+    if (!fp) return fail(SW_E_ARG, std::string("sw_node_db_save: cannot write the manifest in ") + dir);
+    const uint64_t head[4] = {kNodeMagic, S, ndb->n, ndb->residues};
+    bool ok = fwrite(head, 8, 4, fp) == 4;
+    for (size_t s = 0; s < S && ok; s++) {
+      const uint64_t cnt = ndb->global_index[s].size();
+      ok = fwrite(&cnt, 8, 1, fp) == 1 && (cnt == 0 || fwrite(ndb->global_index[s].data(), 4, cnt, fp) == cnt);
+    }
+    if (fclose(fp) != 0) ok = false;
+    if (!ok) return fail(SW_E_ARG, std::string("sw_node_db_save: write error in ") + dir);
+    return SW_OK;
+  });
+}
+
+sw_node_db* sw_node_db_open(sw_node* node, const char* dir) {
+  return guarded<sw_node_db*>(nullptr, [&]() -> sw_node_db* {
+    if (!node || !dir) {
+      fail(SW_E_ARG, "null argument");
+      return nullptr;
+    }
+    const std::string base = std::string(dir) + "/";
+    FILE* fp = fopen((base + "node.swnode").c_str(), "rb");
+    if (!fp) {
+      fail(SW_E_ARG, std::string("sw_node_db_open: no manifest in ") + dir);
+      return nullptr;
+    }
+    std::unique_ptr<sw_node_db, void (*)(sw_node_db*)> ndb(new sw_node_db, node_db_release);
+    uint64_t head[4] = {0, 0, 0, 0};
+    bool ok = fread(head, 8, 4, fp) == 4 && head[0] == kNodeMagic && head[1] == node->devices.size() && head[2] < 0xffffffffull;
+    const size_t S = ok ? (size_t)head[1] : 0;
+    ndb->global_index.assign(S, {});
+    std::vector<uint8_t> seen(ok ? head[2] : 0, 0);
+    for (size_t s = 0; s < S && ok; s++) {
+      uint64_t cnt = 0;
+      ok = fread(&cnt, 8, 1, fp) == 1 && cnt <= head[2];
+      if (!ok) break;
+      ndb->global_index[s].resize(cnt);
+      ok = cnt == 0 || fread(ndb->global_index[s].data(), 4, cnt, fp) == cnt;
+      for (size_t k = 0; k < cnt && ok; k++) {  // every database index exactly once over all shards
+        const uint32_t g = ndb->global_index[s][k];
+        ok = g < head[2] && !seen[g];
+        if (ok) seen[g] = 1;
+      }
+    }
+    fclose(fp);
+    if (ok)
+      for (uint8_t v : seen) ok = ok && v;
+    if (!ok) {
+      fail(SW_E_ARG, std::string("sw_node_db_open: ") + dir + ": bad manifest, or written for a different number of shards (the node has " +
+                         std::to_string(node->devices.size()) + ")");
+      return nullptr;
+    }
+    ndb->ctx = node->ctx;
+    ndb->devices = node->devices;
+    ndb->shards.assign(S, nullptr);
+    ndb->n = head[2];
+    ndb->residues = head[3];
+    const int rc = on_every_shard(S, [&](size_t s) -> int {
+      char name[32];
+      snprintf(name, sizeof name, "shard-%03zu.swdb", s);
+      ndb->shards[s] = db_open_on(ndb->ctx[s], (base + name).c_str());
+      if (!ndb->shards[s]) return SW_E_ARG;
+      if (sw_db_size(ndb->shards[s]) != ndb->global_index[s].size()) return fail(SW_E_ARG, "shard file and manifest disagree");
+      return SW_OK;
     });
     if (rc) return nullptr;
     return ndb.release();

@@ -65,6 +65,14 @@ sw_db *sw_db_create(const char *flat, const uint64_t *offsets, uint64_t n);
 /* Parses a FASTA file the way cli/__main__.py:19-34 does (id = first token after '>', multi-line
  * bodies concatenated). */
 sw_db *sw_db_load_fasta(const char *path);
+/* The packed database on disk: everything sw_db_create computes from raw sequences (validation, length sort,
+ * lane groups, the 2-bit strip stream, the escape list of sequences outside ACGT), stored as it goes to the
+ * device, about a quarter of the FASTA size.  sw_db_open is a read, a consistency check of every table against
+ * the others, and an upload; searches on a re-opened database give identical results.  The input side of the
+ * reference is FASTA parsed on every submission (cli/__main__.py:19-34) and one HTTP GET per sequence per work
+ * package (internal/worker/master_rest_client.go:185-204). */
+int sw_db_save(sw_db *db, const char *path);
+sw_db *sw_db_open(const char *path);
 void sw_db_free(sw_db *db);
 uint64_t sw_db_size(const sw_db *db);
 /* total residues */
@@ -143,6 +151,10 @@ int sw_node_shards(const sw_node *node);
  * and the tiles dealt longest-first to the shard with the fewest residues so far. */
 int sw_shard_plan(const uint64_t *offsets, uint64_t n, int n_shards, uint32_t *shard_of);
 sw_node_db *sw_node_db_create(sw_node *node, const char *flat, const uint64_t *offsets, uint64_t n);
+/* Per-GPU shard files: <dir>/shard-000.swdb ... (sw_db_save of every shard) plus <dir>/node.swnode (which
+ * database index each shard-local index stands for).  sw_node_db_open needs a node with the same number of shards. */
+int sw_node_db_save(sw_node_db *db, const char *dir);
+sw_node_db *sw_node_db_open(sw_node *node, const char *dir);
 void sw_node_db_free(sw_node_db *db);
 uint64_t sw_node_db_size(const sw_node_db *db);
 int sw_node_db_shards(const sw_node_db *db);
