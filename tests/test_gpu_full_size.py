@@ -183,3 +183,87 @@ def test_c5_short_queries_vs_a_million_reads(oracle):
         assert order == [h["target_index"] for h in res[7]]
     finally:
         db.close()
+
+
+def _top_order(scores, k):
+    """(score desc, index asc) over a big numpy score vector without a Python sort of 10^7 items"""
+    scores = np.asarray(scores)
+    kth = np.partition(scores, len(scores) - k)[len(scores) - k]
+    cand = np.flatnonzero(scores >= kth)
+    return [int(i) for i in cand[np.lexsort((cand, -scores[cand].astype(np.int64)))][:k]]
+
+
+def test_c5_real_size_ten_million_reads(oracle):
+    """BASELINE.json configs[4] at its real database size: 10^7 reads of 150 nt (78 125 lane groups, 781 250 strips,
+    a 40 MB score vector), one query and a batch of 8.  Planted reads must come out on top, reported hits are
+    oracle-exact, and the on-device selection equals the host selection over the full score vector."""
+    from dlsa_amd import bridge
+    n, L, nq = 10_000_000, 150, 8
+    flat, offs = bridge.synth(0xC55, n, L, L)
+    flat = flat.copy()
+    qf, qo = bridge.synth(0xC56, nq, L, L)
+    queries = [qf[i * L:(i + 1) * L].copy() for i in range(nq)]
+    rng = np.random.default_rng(0xC5)
+    home = [int(x) for x in rng.choice(n, size=nq, replace=False)]
+    home[0], home[1] = 0, n - 1                         # first and last read of the database
+    for qi in range(nq):                                 # read home[qi] = the query with two substitutions
+        r = queries[qi].copy()
+        for p in (20, 100):
+            r[p] = LUT[(int(np.nonzero(LUT == r[p])[0][0]) + 1) % 4]
+        flat[home[qi] * L:(home[qi] + 1) * L] = r
+    qs = [x.tobytes().decode() for x in queries]
+    tgt = lambda i: flat[i * L:(i + 1) * L].tobytes().decode()  # noqa: E731
+    db = bridge.Database(flat=flat, offsets=offs)
+    try:
+        single = db.search_topk(qs[0], _score(), 5)
+        res = db.search_topk_batch(qs, _score(), 5)
+        assert [h["target_index"] for h in single] == [h["target_index"] for h in res[0]]
+        for qi, hits in enumerate(res):
+            assert hits[0]["target_index"] == home[qi] and len(hits) == 5
+            for h in hits:
+                e = oracle.align("lowmem", qs[qi], tgt(h["target_index"]), *SC)
+                assert (h["score"], h["max_x"], h["max_y"], h["query_aln"], h["target_aln"]) == (
+                    e["score"], e["max_x"], e["max_y"], e["q"], e["t"])
+        scores = db.scores(qs[5], _score())              # 10^7 scores through the host path
+        assert _top_order(scores, 5) == [h["target_index"] for h in res[5]]
+        for i in random.Random(6).sample(range(n), 60) + [0, n - 1, home[5]]:
+            assert int(scores[i]) == oracle.align("lowmem", qs[5], tgt(i), *SC)["score"], i
+    finally:
+        db.close()
+
+
+def test_c3_sharded_path_at_full_size():
+    """BASELINE.json configs[2] through the multi-GPU handle: the 10^6-target length-skewed database over three
+    (logical) shards, 8 of the 32 queries; must equal the unsharded search hit for hit, shards balanced within 2 %."""
+    from dlsa_amd import bridge
+    n, nq, Q = 1_000_000, 8, 1000
+    flat, offs = bridge.synth(0xC31, n, 200, 5000)
+    qf, qo = bridge.synth(0xC32, nq, Q, Q)
+    flat = flat.copy()
+    rng = np.random.default_rng(0xC3)
+    lens = np.diff(offs.astype(np.int64))
+    for qi in range(nq):                                  # one homolog per query
+        idx = int(rng.choice(np.flatnonzero(lens >= 1000)))
+        o = int(offs[idx]) + 5
+        flat[o:o + 900] = _mutate(rng, qf[qi * Q + 50:qi * Q + 950], 0.03)
+    qs = [qf[i * Q:(i + 1) * Q].tobytes().decode() for i in range(nq)]
+    node = bridge.Node(devices=[0, 0, 0])
+    ndb = bridge.NodeDatabase(node, flat=flat, offsets=offs)
+    try:
+        info = ndb.shard_info()
+        res = [i["residues"] for i in info]
+        assert sum(i["n_targets"] for i in info) == n and (max(res) - min(res)) / (sum(res) / 3) < 0.02
+        got = ndb.search_topk_batch(qs, _score(), 5)
+    finally:
+        ndb.close()
+        node.close()
+    db = bridge.Database(flat=flat, offsets=offs)
+    try:
+        ref = db.search_topk_batch(qs, _score(), 5)
+    finally:
+        db.close()
+    key = lambda hits: [(h["target_index"], h["score"], h["max_x"], h["max_y"], h["query_aln"], h["target_aln"]) for h in hits]  # noqa: E731
+    assert [key(a) for a in got] == [key(b) for b in ref]
+    for qi, hits in enumerate(got):
+        _verify(qs[qi], flat[int(offs[hits[0]["target_index"]]):int(offs[hits[0]["target_index"] + 1])].tobytes().decode(),
+                hits[0]["score"], hits[0]["max_x"], hits[0]["max_y"], hits[0]["query_aln"], hits[0]["target_aln"])
