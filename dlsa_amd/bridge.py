@@ -156,6 +156,8 @@ def lib():
         if L.sw_hip_struct_size(which) != C.sizeof(mirror):
             raise SwHipError(f"{mirror.__name__} is {C.sizeof(mirror)} bytes, the library's struct "
                              f"{L.sw_hip_struct_size(which)}: dlsa_amd/bridge.py has fallen behind include/*.h")
+    L.sw_hip_package_stats.argtypes = [C.POINTER(C.c_uint64)]
+    L.sw_hip_package_stats.restype = None
     L.sw_hip_path_params.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
     L.sw_hip_path_params.restype = C.c_int
     L.sw_hip_test_units.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -269,8 +271,16 @@ def align_batch(queries, targets, score, path=0):
     """sw_align_batch: one GPU submission for a list of pairs; returns a list of GoResult/None."""
     L = lib()
     n = len(queries)
-    qs = (C.c_char_p * n)(*[_b(q) for q in queries])
-    ts = (C.c_char_p * n)(*[_b(t) for t in targets])
+    # one C string per distinct Python string: a work package names the same sequence over and over
+    # (worker_impl.go:115-117), and the library groups a package by the pointers it is given
+    enc = {}
+    def cstr(s):
+        b = enc.get(s)
+        if b is None:
+            b = enc[s] = C.create_string_buffer(_b(s))
+        return C.cast(b, C.c_char_p)
+    qs = (C.c_char_p * n)(*[cstr(q) for q in queries])
+    ts = (C.c_char_p * n)(*[cstr(t) for t in targets])
     out = (C.POINTER(CResult) * n)()
     rc = L.sw_align_batch(qs, ts, n, score.c(), path, out)
     if rc != 0:
@@ -527,6 +537,13 @@ class NodeDatabase:
             self.close()
         except Exception:
             pass
+
+
+def package_stats():
+    """sw_hip_package_stats: what the work-package fast path did in the last batch call."""
+    out = (C.c_uint64 * 5)()
+    lib().sw_hip_package_stats(out)
+    return dict(zip(("pairs", "queries", "windows", "rounds", "window_cells"), [int(x) for x in out]))
 
 
 def last_stats():

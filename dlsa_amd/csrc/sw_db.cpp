@@ -38,6 +38,7 @@ struct sw_db {
   ScoreUnit* d_units = nullptr;
   uint32_t n_units = 0, units_S = 0, units_R = 0, units_W = 0;
   uint64_t units_chained = 0;        // units that hand their last H column to the next unit through HBM
+  std::vector<ScoreUnit> h_units;    // host copy of the table currently on the device
   std::vector<uint32_t> generic;  // targets scored by the exact kernel only
   uint32_t max_len = 0;
 };
@@ -586,7 +587,7 @@ bool fast_domain(Scoring sc) {
 // of the device's static scratch array, the unit table is built inside the pre-reserved host arena on every call
 // and the number of workgroups is cut down to what the fixed boundary ring can serve.
 int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwords, size_t n_qwords, uint32_t Q,
-                      Scoring sc, HostArena* arena = nullptr) {
+                      Scoring sc, HostArena* arena = nullptr, bool persist = false) {
   const uint32_t nblk = (Q + kScoreB - 1) / kScoreB;
   const size_t Qpad = (size_t)nblk * kScoreB;
   const uint32_t W = (uint32_t)score_waves_per_group(db->n_elems, c.cus);
@@ -611,9 +612,13 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
     if (ring_fit < (uint64_t)ring_min + S) S = (uint32_t)std::max<uint64_t>(8, ring_fit > ring_min ? ring_fit - ring_min : 0);
     if (const char* e = getenv("SW_HIP_SCORE_LANES")) S = std::min(16384, std::max(1, atoi(e)));  // experiments
     ring_slots = S + max_wg * (1 + ahead) + 8;
+    // persist: every unit keeps a ring slot of its own (slot = ticket), so the boundary columns between units
+    // survive the launch -- the work-package fast path re-enters the matrix at them (sw_package.cpp)
+    if (persist) ring_slots = (uint32_t)std::min<size_t>(0x7fffffffu, units_bound(db->n_elems, db->groups.size(), W, max_wg) + 1);
     if (db->units_S != S || db->units_R != ring_slots || db->units_W != W || !db->d_units) {
       std::vector<ScoreUnit> units;
       build_units(db, W, S, ring_slots, max_wg, units, &db->units_chained);
+      db->h_units = units;
       if (db->d_units) (void)hipFree(db->d_units);
       db->d_units = nullptr;
       if (hipMalloc(&db->d_units, std::max<size_t>(units.size(), 1) * sizeof(ScoreUnit)) != hipSuccess)
@@ -660,7 +665,8 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
   int rc;
   if ((rc = ws.qwords.ensure(n_qwords * 4))) return rc;
   if ((rc = ws.slot_scores.ensure(db->slot_target.size() * 4))) return rc;
-  if ((rc = ws.gbound.ensure((size_t)ring_slots * gb_stride * 4))) return rc;
+  if ((rc = ws.gbound.ensure((size_t)(persist ? n_units : ring_slots) * gb_stride * 4))) return rc;
+  if (persist && (rc = ws.strip_best.ensure(std::max<size_t>((size_t)db->n_elems * 256, 256)))) return rc;
   if ((rc = ws.ticket.ensure(256))) return rc;
   if ((rc = ws.prog.ensure(std::max<size_t>((size_t)n_units * 8, 16)))) return rc;
   HIPCK(hipMemcpyAsync(ws.qwords.p, qwords, n_qwords * 4, hipMemcpyHostToDevice, c.stream));
@@ -683,6 +689,7 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
   p.gbound = (uint32_t*)ws.gbound.p;
   p.gbound_stride = gb_stride;
   p.ring_slots = ring_slots;
+  p.strip_best = persist ? (uint32_t*)ws.strip_best.p : nullptr;
   p.prog = (uint32_t*)ws.prog.p;
   p.ticket = (uint32_t*)ws.ticket.p;
   p.err = (uint32_t*)ws.ticket.p + 32;
@@ -901,6 +908,35 @@ bool swhip::prep_query(const char* query, QueryPrep& qp) {
     qp.qwords[i / kScoreB] |= (uint32_t)code << (2 * (i % kScoreB));
   }
   return true;
+}
+
+// ---- a score pass whose inter-unit boundary columns stay resident (the work-package fast path, sw_package.cpp) -------
+int swhip::db_score_persist_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, Scoring sc, PersistPass& out) {
+  if (!fast_path(db, qp, sc)) return fail(SW_E_DOMAIN, "internal: persist pass outside the packed kernel's domain");
+  const uint32_t Q = (uint32_t)qp.d.sym.size();
+  StreamDrain drain(c.stream);
+  int rc = score_pass_locked(c, ws, db, qp.qwords.data(), qp.qwords.size(), Q, sc, nullptr, true);
+  if (rc) return rc;
+  out.slot.resize(db->slot_target.size());
+  out.strip_best.resize((size_t)db->n_elems * 64);
+  uint32_t kerr = 0;
+  HIPCK(hipMemcpyAsync(out.slot.data(), ws.slot_scores.p, out.slot.size() * 4, hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipMemcpyAsync(out.strip_best.data(), ws.strip_best.p, out.strip_best.size() * 4, hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipMemcpyAsync(&kerr, (uint32_t*)ws.ticket.p + 32, 4, hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipStreamSynchronize(c.stream));
+  if ((rc = score_pass_finish_locked(c, db, Q, kerr))) return rc;
+  out.units = &db->h_units;
+  out.groups = &db->groups;
+  out.slot_target = &db->slot_target;
+  out.d_ring = (const uint32_t*)ws.gbound.p;
+  out.ring_stride = (size_t)((Q + kScoreB - 1) / kScoreB) * kScoreB * 64;
+  out.n_elems = db->n_elems;
+  return SW_OK;
+}
+size_t swhip::db_persist_ring_bytes(const sw_db* db, uint32_t Q, int cus) {
+  const uint32_t W = (uint32_t)score_waves_per_group(db->n_elems, cus);
+  const size_t n_units = units_bound(db->n_elems, db->groups.size(), W, (uint32_t)cus * (uint32_t)score_workgroups_per_cu((int)W));
+  return n_units * (size_t)((Q + kScoreB - 1) / kScoreB) * kScoreB * 256;
 }
 
 // ---- the two phases of a search (used by the single-database entry points below and by sw_node.cpp) -------------

@@ -91,7 +91,7 @@ __device__ __forceinline__ void exact_steps16(const uint32_t (&qs)[RPL], const b
                                               int (&bestv)[RPL], uint32_t (&bestj)[RPL], uint32_t (&acc)[RPL],
                                               int& top_prev, int& last_out, int& tcur, int (&hist)[16], int& jv,
                                               int bcur, int tblk, int match, int miss, int gap, uint32_t lim0,
-                                              uint32_t Tlim) {
+                                              uint32_t Tlim, const int (&leftv)[RPL]) {
 #pragma unroll
   for (int k4 = 0; k4 < 16; k4++) {
     const int s_b = __builtin_amdgcn_readlane(bcur, k4);
@@ -112,17 +112,22 @@ __device__ __forceinline__ void exact_steps16(const uint32_t (&qs)[RPL], const b
 #pragma unroll
     for (int r = 0; r < RPL; r++) {
       int hn = max(m[r], upg);
+      int hb = hn;  // what competes for the best cell
       if (MASK) {
         const uint32_t lim = (r == 0) ? lim0 : Tlim;
         const bool act = valid[r] && jv >= 1 && (uint32_t)jv <= lim;
-        hn = act ? hn : 0;
+        // column 0 of a window holds the known boundary column H(x, col0) (zero for a whole matrix): every lane
+        // passes through jv == 0 one step before its first real column, which is what puts the boundary into
+        // h[] (the next step's `left`), into the row above's diagonal and into the lane below's top_prev
+        hn = act ? hn : (jv == 0 ? leftv[r] : 0);
+        hb = act ? hn : 0;
       }
       if (DIRS) {
         // bit 1: up >= left; bit 0: the diagonal wins (for H > 0: H == diag + s  <=>  diag + s >= max(up, left) + gap)
         acc[r] = push_dir_bits(acc[r], upg, lfg[r], hn, d[r]);
       }
-      if (hn > bestv[r]) bestj[r] = (uint32_t)jv;  // strict: the first (smallest j) maximal cell of the row
-      bestv[r] = max(bestv[r], hn);
+      if (hb > bestv[r]) bestj[r] = (uint32_t)jv;  // strict: the first (smallest j) maximal cell of the row
+      bestv[r] = max(bestv[r], hb);
       h[r] = hn;
       upg = hn + gap;
     }
@@ -153,21 +158,25 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
   const uint32_t ibase = strip * SH + lane * RPL;  // 0-based first row of this lane
   uint32_t qs[RPL];
   bool valid[RPL];
-  int h[RPL], bestv[RPL];
+  int h[RPL], bestv[RPL], leftv[RPL];
   uint32_t bestj[RPL], acc[RPL];
 #pragma unroll
   for (int r = 0; r < RPL; r++) {
     uint32_t i = ibase + r;
     valid[r] = i < Q;
     qs[r] = valid[r] ? P.q[i] : 0x10000u;  // never equals a u16 symbol
-    h[r] = 0;
+    leftv[r] = (P.left && valid[r]) ? (int)((P.left[(size_t)i * 64] >> P.left_shift) & 0xffffu) : 0;
+    h[r] = leftv[r];  // lane 0 starts at column 1 and never passes through column 0: its `left` is the boundary now
     bestv[r] = 0;
     bestj[r] = 0;
     acc[r] = 0;
   }
   const bool row1_lane = (strip == 0) && (lane == 0);
   const uint32_t lim0 = row1_lane ? P.T0 : P.Tlim;  // column limit of this lane's row r == 0
-  int top_prev = 0, last_out = 0;
+  // ... and so is its first diagonal: H(row above lane 0's first row, col0).  (The other lanes get both through the
+  // wavefront: every lane above them is forced to the boundary column when it passes column 0.)
+  int top_prev = (P.left && lane == 0 && ibase > 0) ? (int)((P.left[(size_t)(ibase - 1) * 64] >> P.left_shift) & 0xffffu) : 0;
+  int last_out = h[RPL - 1];  // lane 1's first diagonal is lane 0's last row at column 0: the boundary again
   int hist[16];
   int tcur = 0x20000;
   int jv = 1 - lane;  // the column this lane works on
@@ -198,12 +207,14 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
       bnext = fetch_bnd(g + 1);
       tnext = fetch_t(g + 1);
     }
-    if (plain && g * 16 + 16 <= mincol)
+    // (a window with a boundary column runs masked while any lane is still at or left of column 0: lane 63
+    // reaches column 1 at step 63)
+    if (plain && g * 16 + 16 <= mincol && !(P.left && g < 4))
       exact_steps16<RPL, DIRS, false>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
-                                 match, miss, gap, lim0, P.Tlim);
+                                 match, miss, gap, lim0, P.Tlim, leftv);
     else
       exact_steps16<RPL, DIRS, true>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
-                                match, miss, gap, lim0, P.Tlim);
+                                match, miss, gap, lim0, P.Tlim, leftv);
     if (DIRS) {
       uint32_t* w = P.dirs + ((size_t)(strip * P.nkb + g) * RPL) * 64 + lane;
 #pragma unroll
@@ -231,7 +242,7 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
   }
 #pragma unroll
   for (int r = 0; r < RPL; r++) {
-    const uint64_t key = order_key(ibase + r + 1, bestj[r], T, P.phaseQp, P.straight);
+    const uint64_t key = order_key(ibase + r + 1, bestj[r] + P.col0, P.Tfull ? P.Tfull : T, P.phaseQp, P.straight);
     if (bestv[r] > gbv || (bestv[r] == gbv && bestv[r] > 0 && key < gkey)) {
       gbv = bestv[r];
       gkey = key;
@@ -303,12 +314,16 @@ __global__ void __launch_bounds__(64) sw_exact_kernel(ExactWork W, int match, in
     if (gbv > 0) {
       bx = (uint32_t)(gkey & 0x7fffffffu);
       const uint32_t hi = (uint32_t)((gkey >> 31) & 0xffffffffu);
-      bj = P.straight ? hi : hi - bx;
+      bj = (P.straight ? hi : hi - bx) - P.col0;  // window-local
     }
     ExactOut* out = W.outs + p;
     out->score = gbv;
     out->bx = bx;
     out->bj = bj;
+    out->key_lo = (uint32_t)gkey;
+    out->key_hi = (uint32_t)(gkey >> 32);
+    out->end_x = out->end_j = 0;
+    out->end_H = 0;
     out->nops = __hip_atomic_load(W.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0xffffffffu : 0;
   }
 }
@@ -336,11 +351,14 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
   const ExactPair P = pairs[p];
   if (!P.dirs || !P.ops) return;
   if (outs[p].nops == 0xffffffffu) return;  // the fill kernel reported a hand-over time-out
-  int H = __builtin_amdgcn_readfirstlane(outs[p].score);
-  const uint32_t bx = (uint32_t)__builtin_amdgcn_readfirstlane((int)outs[p].bx);
-  const uint32_t bj = (uint32_t)__builtin_amdgcn_readfirstlane((int)outs[p].bj);
+  const bool resumed = P.walk_x != 0;  // continue a traceback that left the window to the right through its column 0
+  int H = __builtin_amdgcn_readfirstlane(resumed ? P.walk_H : outs[p].score);
+  const uint32_t bx = (uint32_t)__builtin_amdgcn_readfirstlane((int)(resumed ? P.walk_x : outs[p].bx));
+  const uint32_t bj = (uint32_t)__builtin_amdgcn_readfirstlane((int)(resumed ? P.walk_j : outs[p].bj));
   const uint32_t cap = P.Q + P.T;
   uint32_t nops = 0;
+  uint32_t end_x = bx, end_j = bj;
+  int end_H = H;
   if (H > 0 && bx > 0 && bj > 0) {
     // wave-uniform walk state: strip, row inside the strip, target index j - 1
     uint32_t strip = (bx - 1) / SH;
@@ -430,15 +448,28 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
           break;
         }
         if (within < 0) {  // into the strip above (or off the top edge)
-          if (strip == 0) go = false;
+          if (strip == 0) {
+            go = false;
+            within = -1;  // row 0
+            break;
+          }
           strip--;
           within = SH - 1;
           break;
         }
       }
     }
+    // where the walk stopped (row 1-based, window-local column; column 0 = the window's boundary column)
+    end_x = (uint32_t)((int)(strip * SH) + within + 1);
+    end_j = (uint32_t)(jm1 + 1);
+    end_H = H;
   }
-  if (lane == 0) outs[p].nops = nops;
+  if (lane == 0) {
+    outs[p].nops = nops;
+    outs[p].end_x = end_x;
+    outs[p].end_j = end_j;
+    outs[p].end_H = end_H;
+  }
 }
 
 }  // namespace

@@ -62,6 +62,7 @@ struct Workspace {
   HostBuf h_in, h_out;                                     // ... its host staging buffers
   DevBuf sel_hist, sel_ctr, sel_rerun, sel_cand, sel_tie;  // device-side top-k selection
   DevBuf qwords, slot_scores, gbound, ticket, prog, units; // score path
+  DevBuf strip_best;                                       // ... per-strip maxima (work-package fast path)
   void release();
 };
 
@@ -148,12 +149,22 @@ struct PairSpec {
   // optional: small dense ids of the two sequences within the submission (equal id <=> same sequence); lets the
   // driver upload every distinct sequence once without hashing 10^5 pointers.  UINT32_MAX: look the pointer up.
   uint32_t qid = UINT32_MAX, tid = UINT32_MAX;
+  // a WINDOW of the pair's matrix (ExactPair in sw_internal.h): rows 1..Q, columns col0+1 .. col0+T; t points at the
+  // symbol of column col0+1; Qfull / Tfull are the lengths that decide the reference's path quirks and tie order
+  uint32_t col0 = 0, Qfull = 0, Tfull = 0;
+  const uint32_t* left = nullptr;  // device pointer into the score kernel's boundary ring (nullptr: zeros)
+  uint32_t left_shift = 0;
+  uint32_t walk_x = 0, walk_j = 0;  // != 0: the walker resumes here with H = walk_H
+  int32_t walk_H = 0;
 };
 struct PairOut {
   int32_t score = 0;
   uint32_t bx = 0, bj = 0;
   size_t ops_off = 0;  // traceback ops (last alignment column first) at arena[ops_off .. ops_off + nops)
   uint32_t nops = 0;
+  uint32_t end_x = 0, end_j = 0;  // where the walker stopped (window-local column; 0 = the boundary column)
+  int32_t end_H = 0;
+  uint64_t key = ~0ull;           // discovery-order key of the best cell (global column)
 };
 struct PathParams {
   uint32_t Tlim, T0, phaseQp, straight;
@@ -163,6 +174,17 @@ bool ring_div_by_zero(int path, uint32_t Q, uint32_t T, Scoring sc);
 // Caller holds the context's lock.
 int run_exact(Context& c, Workspace& ws, const PairSpec* specs, size_t n, Scoring sc, bool want_trace, PairOut* outs,
               std::vector<uint8_t>* arena = nullptr);
+
+// ---- the work-package fast path (sw_package.cpp) ------------------------------------------------------------------
+// For the pairs it is eligible for, fills po[k] (global end cell, score, ops appended to `arena`) and sets
+// handled[k]; everything else is left to the whole-matrix path.  dec: the distinct decoded sequences of the batch;
+// pair_q / pair_t: per pair, indices into dec.  Takes the default context's lock itself.
+int align_windows(const std::vector<Decoded>& dec, const std::vector<uint32_t>& pair_q, const std::vector<uint32_t>& pair_t,
+                  Scoring sc, std::vector<PairOut>& po, std::vector<uint8_t>& arena, std::vector<uint8_t>& handled);
+struct PackageStats {
+  uint64_t pairs = 0, queries = 0, windows = 0, rounds = 0, window_cells = 0;
+};
+extern PackageStats g_package_stats;
 
 // ---- result strings ---------------------------------------------------------------------------------------------
 char* str_alloc(size_t n);
@@ -223,6 +245,20 @@ int db_topk_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring sc, size
 // (target_index = the database-local index; strings owned by the caller).  Takes the context lock.
 int db_align_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring sc, const std::vector<HitRef>& refs, sw_hit* hits_out);
 Context* db_context(sw_db* db);
+// A score pass that leaves every inter-unit boundary column resident (ring slot = ticket) and reports, per strip
+// of the stream, the packed maxima of that strip alone.  Pointers stay valid until the next pass on the context.
+struct PersistPass {
+  std::vector<int32_t> slot;            // per slot: best score (32767 = saturated)
+  std::vector<uint32_t> strip_best;     // per strip 64 dwords (lo half: slot lane, hi half: slot 64 + lane)
+  const std::vector<ScoreUnit>* units = nullptr;   // ticket order
+  const std::vector<ScoreGroup>* groups = nullptr;
+  const std::vector<uint32_t>* slot_target = nullptr;
+  const uint32_t* d_ring = nullptr;     // device: boundary column of ticket u at d_ring + u * ring_stride (+ lane)
+  size_t ring_stride = 0;               // dwords
+  uint32_t n_elems = 0;
+};
+int db_score_persist_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, Scoring sc, PersistPass& out);
+size_t db_persist_ring_bytes(const sw_db* db, uint32_t Q, int cus);
 sw_db* db_create_on(Context* ctx, const char* flat, const uint64_t* offsets, uint64_t n);
 sw_db* db_create_owned(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off);
 sw_db* db_open_on(Context* ctx, const char* path);  // a file written by sw_db_save

@@ -63,12 +63,31 @@ struct ExactPair {
   uint8_t* ops;       // traceback ops written by the walker (capacity Q + T)
   uint32_t first_unit; // record index of this pair's strip 0 (records are in (pair, strip) order; tickets: ExactWork::unit_order)
   uint32_t n_units;    // max(number of strips, 1)
+  // ---- a WINDOW of the matrix (the work-package fast path, sw_lib.cpp: align_windows): the pair above is rows
+  // 1..Q x columns col0+1 .. col0+T of a larger matrix whose column col0 is known.  t points at the symbol of
+  // column col0+1; T, Tlim, T0 are local (already reduced by col0).
+  const uint32_t* left;  // nullptr: H(x, col0) = 0 (col0 == 0).  Else the boundary column as the score kernel left
+                         // it in its ring: row x (1-based) is the int16 half `left_shift` of left[(x - 1) * 64]
+  uint32_t left_shift;   // 0 or 16
+  uint32_t col0;         // columns left of the window (added to j in the discovery-order key)
+  uint32_t Tfull;        // length of the whole target (the key's phase rule compares j with it); 0: T
+  // the walker starts at (walk_x, walk_j, walk_H) instead of the pair's best cell when walk_x != 0 (a traceback
+  // that continues from the window to its right)
+  uint32_t walk_x, walk_j;
+  int32_t walk_H;
+  uint32_t pad_;
 };
 struct ExactOut {
   int32_t score;  // H of the best cell (0: no hit)
   uint32_t bx;    // best cell, 1-based query index (0: none)
-  uint32_t bj;    // best cell, 1-based target index
+  uint32_t bj;    // best cell, 1-based target index (window-local)
   uint32_t nops;  // number of traceback ops (walker)
+  // where and with which H the walker stopped: end_H > 0 with end_j == 0 means it reached the window's left edge
+  // (column col0) at row end_x and the traceback continues in the window to the left
+  uint32_t end_x, end_j;
+  int32_t end_H;
+  uint32_t key_lo, key_hi;  // discovery-order key of the best cell (order_key, global j): lets the host choose
+  uint32_t pad_;            // between windows of one pair
 };
 // Rows per lane (rpl) of the exact kernel: 4, 2 or 1, i.e. strips of 256, 128 or 64 query rows -- chosen per
 // submission (exact_choose_rpl): 4 does the least work per cell (batches of many pairs), smaller strips give a
@@ -150,6 +169,8 @@ struct ScoreParams {
   uint32_t* gbound;           // ring of inter-unit boundary columns: ring_slots * gbound_stride dwords
   uint64_t gbound_stride;     // dwords per ring slot (Q_pad * 64)
   uint32_t ring_slots;
+  uint32_t* strip_best;       // nullptr, or per strip of the stream 64 dwords: the packed maxima of that strip alone
+                              // (which 16 columns of which target reach its score: the work-package fast path)
   uint32_t* prog;             // 2 per unit: boundary blocks published / input slot released (zeroed)
   uint32_t* ticket;           // work counter (zeroed before launch)
   uint32_t* err;              // set != 0 if a dependency wait timed out (zeroed before launch)

@@ -194,7 +194,7 @@ swhip::CtxLock::CtxLock(Context* ctx) : c(ctx) {
 }
 void swhip::Workspace::release() {
   for (DevBuf* b : {&xin, &xzero, &xout, &dirs, &xrecs, &sel_hist, &sel_ctr, &sel_rerun, &sel_cand, &sel_tie, &qwords,
-                    &slot_scores, &gbound, &ticket, &prog, &units})
+                    &slot_scores, &gbound, &ticket, &prog, &units, &strip_best})
     b->release();
   h_in.release();
   h_out.release();
@@ -271,8 +271,8 @@ int run_exact_chunk(Context& c, Workspace& ws, const PairSpec* specs, size_t beg
   if (n == 0) return SW_OK;
   StageTimer tm(n);
   // symbol pool: every distinct sequence once (a database search shares one query)
-  std::unordered_map<const uint16_t*, size_t> seen;
-  std::vector<size_t> off_by_id;
+  std::unordered_map<const uint16_t*, size_t> seen;  // pointer -> index into copies
+  std::vector<size_t> copy_by_id;                    // id -> index into copies
   struct SeqCopy {
     const uint16_t* p;
     uint32_t len;
@@ -280,19 +280,22 @@ int run_exact_chunk(Context& c, Workspace& ws, const PairSpec* specs, size_t beg
   };
   std::vector<SeqCopy> copies;  // distinct sequences, copied straight into the pinned staging buffer below
   size_t pool_syms = 0;
+  // (a cached copy is reused only for the SAME length: windows of one pair name prefixes of one query and
+  // different stretches of one target)
   auto add_seq = [&](const uint16_t* p, uint32_t len, uint32_t id) -> size_t {
     if (id != UINT32_MAX) {
-      if (id >= off_by_id.size()) off_by_id.resize((size_t)id + 1 + off_by_id.size() / 2, SIZE_MAX);
-      if (off_by_id[id] != SIZE_MAX) return off_by_id[id];
+      if (id >= copy_by_id.size()) copy_by_id.resize((size_t)id + 1 + copy_by_id.size() / 2, SIZE_MAX);
+      if (copy_by_id[id] != SIZE_MAX && copies[copy_by_id[id]].len == len && copies[copy_by_id[id]].p == p)
+        return copies[copy_by_id[id]].off;
     } else {
       auto it = seen.find(p);
-      if (it != seen.end()) return it->second;
+      if (it != seen.end() && copies[it->second].len == len) return copies[it->second].off;
     }
     const size_t off = pool_syms;
     copies.push_back(SeqCopy{p, len, off});
     pool_syms += (len + 1u) & ~(size_t)1;
-    if (id != UINT32_MAX) off_by_id[id] = off;
-    else seen.emplace(p, off);
+    if (id != UINT32_MAX) copy_by_id[id] = copies.size() - 1;
+    else seen[p] = copies.size() - 1;
     return off;
   };
   std::vector<ExactPair> hp(n);
@@ -305,10 +308,21 @@ int run_exact_chunk(Context& c, Workspace& ws, const PairSpec* specs, size_t beg
     const PairSpec& s = specs[begin + i];
     qoff[i] = add_seq(s.q, s.Q, s.qid);
     toff[i] = add_seq(s.t, s.T, s.tid);
-    PathParams pp = resolve_path(s.path, s.Q, s.T);
+    PathParams pp = resolve_path(s.path, s.Qfull ? s.Qfull : s.Q, s.Tfull ? s.Tfull : s.T);
+    if (s.Tfull) {  // a window: the column limits are global, the kernel counts columns from col0
+      pp.Tlim = pp.Tlim > s.col0 ? std::min(pp.Tlim - s.col0, s.T) : 0;
+      pp.T0 = pp.T0 > s.col0 ? std::min(pp.T0 - s.col0, s.T) : 0;
+    }
     ExactPair& e = hp[i];
     e.Q = s.Q;
     e.T = s.T;
+    e.left = s.left;
+    e.left_shift = s.left_shift;
+    e.col0 = s.col0;
+    e.Tfull = s.Tfull;
+    e.walk_x = s.walk_x;
+    e.walk_j = s.walk_j;
+    e.walk_H = s.walk_H;
     e.Tlim = pp.Tlim;
     e.T0 = pp.T0;
     e.phaseQp = pp.phaseQp;
@@ -459,6 +473,10 @@ int run_exact_chunk(Context& c, Workspace& ws, const PairSpec* specs, size_t beg
     o.score = ho[i].score;
     o.bx = ho[i].bx;
     o.bj = ho[i].bj;
+    o.end_x = ho[i].end_x;
+    o.end_j = ho[i].end_j;
+    o.end_H = ho[i].end_H;
+    o.key = ((uint64_t)ho[i].key_hi << 32) | ho[i].key_lo;
     c.stats.exact_cells += (uint64_t)specs[begin + i].Q * specs[begin + i].T;
     if (want_trace && ho[i].nops) {
       o.ops_off = arena_base + (size_t)(hp[i].ops - (d_out + out_ops));
@@ -755,11 +773,32 @@ int align_many(const char* const* queries, const char* const* targets, size_t n,
   std::vector<PairOut> po(specs.size());
   std::vector<uint8_t> arena;
   tm.lap("specs");
-  {
-    CtxLock L(-1);
-    if (L.rc) return L.rc;
-    const int rc = run_exact(*L.c, L.c->ws, specs.data(), specs.size(), sc, true, po.data(), &arena);
+  // The work-package fast path (sw_package.cpp) takes the pairs it is eligible for: long ACGT targets on the ring
+  // path, filled by the packed score kernel and traced inside windows.  Same results, by construction and by test.
+  std::vector<uint8_t> handled(specs.size(), 0);
+  if (path == SW_PATH_LOW_MEMORY && !specs.empty()) {
+    std::vector<uint32_t> pq(specs.size()), pt(specs.size());
+    for (size_t k = 0; k < specs.size(); k++) pq[k] = qi[idx[k]], pt[k] = ti[idx[k]];
+    const int rc = align_windows(dec, pq, pt, sc, po, arena, handled);
     if (rc) return rc;
+    tm.lap("windows");
+  }
+  {
+    std::vector<PairSpec> rest;
+    std::vector<size_t> rest_k;
+    for (size_t k = 0; k < specs.size(); k++)
+      if (!handled[k]) {
+        rest.push_back(specs[k]);
+        rest_k.push_back(k);
+      }
+    if (!rest.empty()) {
+      std::vector<PairOut> ro(rest.size());
+      CtxLock L(-1);
+      if (L.rc) return L.rc;
+      const int rc = run_exact(*L.c, L.c->ws, rest.data(), rest.size(), sc, true, ro.data(), &arena);
+      if (rc) return rc;
+      for (size_t r = 0; r < rest.size(); r++) po[rest_k[r]] = ro[r];
+    }
   }
   tm.lap("run_exact");
   parallel_ranges(specs.size(), arena.size() * 4, [&](size_t lo, size_t hi) {

@@ -1,0 +1,91 @@
+"""The work-package fast path (dlsa_amd/csrc/sw_package.cpp) against the oracle: pairs of the reference's own synthetic
+shape (utils/generate_synthetic_data.py: short queries, long targets) through sw_align_batch / sw_execute_work must
+give the oracle's find_alignment_low_memory result field by field -- score, end coordinates, both aligned strings --
+although the matrix is filled by the packed score kernel and only windows of it are re-entered with direction bits.
+Planted homologs make alignments that cross several windows (continuation rounds), duplicated fragments make equal
+maxima in different windows (tie-breaking across windows)."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SC = (-1, 2, -1)
+
+
+def _rnd(rng, n, alpha="ACGT"):
+    return "".join(rng.choice(alpha) for _ in range(n))
+
+
+def _mut(rng, s, rate):
+    return "".join((rng.choice("ACGT") if rng.random() < rate else c) for c in s)
+
+
+def _check(oracle, res, q, t, sc=SC):
+    e = oracle.align("lowmem", q, t, *sc)
+    assert res is not None
+    assert (res.score, res.max_x, res.max_y, res.query, res.target) == (e["score"], e["max_x"], e["max_y"], e["q"], e["t"])
+
+
+def test_package_of_long_targets_matches_the_oracle(oracle):
+    import dlsa_amd
+    from dlsa_amd import bridge
+    rng = random.Random(41)
+    s = dlsa_amd.AlignmentScore(SC[1], SC[2], SC[0])
+    queries = [_rnd(rng, n) for n in (200, 517, 1000, 64)]
+    targets = [_rnd(rng, rng.randint(3000, 9000)) for _ in range(20)] + [_rnd(rng, 60000), _rnd(rng, 4096), _rnd(rng, 2048)]
+    # homologs: long alignments that cross unit boundaries (every 256 target columns) -> continuation rounds
+    targets[0] = targets[0][:1000] + _mut(rng, queries[2][50:950], 0.04) + targets[0][1000:]
+    targets[1] = targets[1][:250] + queries[1][10:500] + targets[1][250:]
+    # the same fragment twice: equal maxima in different windows, the reference takes the first in its order
+    frag = queries[0][20:180]
+    targets[2] = targets[2][:300] + frag + targets[2][300:2000] + frag + targets[2][2000:]
+    # ... and at the very end / very beginning of a target
+    targets[3] = targets[3] + queries[0][:150]
+    targets[4] = queries[1][100:400] + targets[4]
+    qs = [q for q in queries for _ in targets]
+    ts = targets * len(queries)
+    res = bridge.align_batch(qs, ts, s, 0)
+    st = bridge.package_stats()
+    assert st["pairs"] == len(qs) and st["queries"] == len(queries)
+    assert st["rounds"] > len(queries)                       # some traceback continued to the left
+    total = sum(len(q) * len(t) for q, t in zip(qs, ts))
+    assert st["window_cells"] < 0.25 * total                 # the exact kernel saw a fraction of the matrix
+    for r, q, t in zip(res, qs, ts):
+        _check(oracle, r, q, t)
+
+
+def test_package_mixed_with_ineligible_pairs_and_other_scorings(oracle):
+    """Eligible and ineligible pairs in one batch (short targets, non-ACGT, T < 2Q): each takes its own path, results
+    in input order; steeper scorings; the worker's ExecuteWork entry."""
+    import dlsa_amd
+    from dlsa_amd import bridge, worker
+    rng = random.Random(42)
+    q1, q2 = _rnd(rng, 300), _rnd(rng, 900)
+    long_t = [_rnd(rng, rng.randint(20000, 40000)) for _ in range(12)]
+    long_t[5] = long_t[5][:7000] + _mut(rng, q2[:800], 0.1) + long_t[5][7000:]
+    long_t[6] = long_t[6][:255] + q1[40:260] + long_t[6][255:]          # ends right after a unit boundary
+    odd = [_rnd(rng, 500), "N" * 10 + _rnd(rng, 5000), _rnd(rng, 1500), ""]
+    targets = long_t + odd
+    for sc in ((-1, 2, -1), (-3, 5, -2), (-2, 1, -1)):
+        s = dlsa_amd.AlignmentScore(sc[1], sc[2], sc[0])
+        qs = [q for q in (q1, q2) for _ in targets]
+        ts = targets * 2
+        res = bridge.align_batch(qs, ts, s, 0)
+        st = bridge.package_stats()
+        assert st["pairs"] == 2 * len(long_t), st
+        for r, q, t in zip(res, qs, ts):
+            _check(oracle, r, q, t, sc)
+    # the worker's entry point (sw_execute_work): same path underneath
+    seqs = {f"s{i}": t for i, t in enumerate(long_t)}
+    seqs["q"] = q1
+    pkg = worker.CompleteWorkPackage(id="w", job_id="j", queries=[worker.QueryTargetType("q", f"s{i}") for i in range(len(long_t))],
+                                     match_score=2, mismatch_penalty=1, gap_penalty=1, sequences=seqs)
+    out = worker.Worker().align(pkg, pkg.queries)
+    assert bridge.package_stats()["pairs"] == len(long_t)
+    for d, t in zip(out, long_t):
+        e = oracle.align("lowmem", q1, t, -1, 2, -1)
+        a = d.alignment
+        assert (a.query_alignment, a.target_alignment, a.score, a.maxX, a.maxY, a.length) == (
+            e["q"], e["t"], e["score"], e["max_x"], e["max_y"], len(e["q"]))
