@@ -541,9 +541,9 @@ class NodeDatabase:
 
 def package_stats():
     """sw_hip_package_stats: what the work-package fast path did in the last batch call."""
-    out = (C.c_uint64 * 5)()
+    out = (C.c_uint64 * 7)()
     lib().sw_hip_package_stats(out)
-    return dict(zip(("pairs", "queries", "windows", "rounds", "window_cells"), [int(x) for x in out]))
+    return dict(zip(("pairs", "queries", "windows", "rounds", "window_cells", "chunks", "chunk_escapes"), [int(x) for x in out]))
 
 
 def last_stats():

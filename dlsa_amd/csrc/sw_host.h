@@ -182,7 +182,7 @@ int run_exact(Context& c, Workspace& ws, const PairSpec* specs, size_t n, Scorin
 int align_windows(const std::vector<Decoded>& dec, const std::vector<uint32_t>& pair_q, const std::vector<uint32_t>& pair_t,
                   Scoring sc, std::vector<PairOut>& po, std::vector<uint8_t>& arena, std::vector<uint8_t>& handled);
 struct PackageStats {
-  uint64_t pairs = 0, queries = 0, windows = 0, rounds = 0, window_cells = 0;
+  uint64_t pairs = 0, queries = 0, windows = 0, rounds = 0, window_cells = 0, chunks = 0, chunk_escapes = 0;
 };
 extern PackageStats g_package_stats;
 

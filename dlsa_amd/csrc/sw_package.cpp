@@ -45,14 +45,6 @@ struct DbHolder {
   }
 };
 
-// one window of one pair, as submitted to the exact kernel
-struct Win {
-  size_t pair;     // index into the fast path's pair list
-  uint32_t unit;   // ticket of the work unit the window lies in
-  uint32_t col0;   // columns left of the window
-  uint32_t cols;   // window width
-};
-
 }  // namespace
 
 namespace swhip {
@@ -100,22 +92,56 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
   }
   for (auto& set : by_targets) {
     const std::vector<uint32_t>& tids = set.first;
+    // ---- chunks.  A long target is a long chain of dependent strips for the score kernel (T / 16 hops, each one
+    // block of rows long): few long targets leave the GPU idle.  A target is therefore cut into overlapping CHUNKS
+    // that enter the temporary database as sequences of their own.  An alignment spans at most
+    // O = Q + floor(Q * match / |gap|) target columns (it has at most Q query symbols, and every target-only column
+    // costs |gap| of at most Q * match gained -- the bound behind the reference's ring buffer,
+    // rust/src/algorithm/mod.rs:232-242), so with O columns of overlap every alignment that ENDS in a chunk's own
+    // region lies inside the chunk: there the chunk's H equals the full matrix's H on the whole traceback path, and
+    // every decision of the traceback falls the same way (the predecessor that wins is on the path, hence exact;
+    // the losers can only be smaller).  Own regions tile the target, so score, first end cell and path are exact.
+    uint32_t Qmax = 0;
+    for (uint32_t qid : set.second) Qmax = std::max<uint32_t>(Qmax, (uint32_t)dec[qid].sym.size());
+    const uint64_t O = (uint64_t)Qmax + (uint64_t)Qmax * (uint64_t)sc.match / (uint64_t)(-sc.gap) + 1;
+    static const double chunk_mult = getenv("SW_HIP_CHUNK_MULT") ? atof(getenv("SW_HIP_CHUNK_MULT")) : 2.0;  // experiments
+    const uint64_t S = std::max<uint64_t>((uint64_t)(chunk_mult * (double)O), 4096);
+    struct Chunk {
+      uint32_t tid;     // index into dec
+      uint32_t start;   // first target column of the chunk (0-based)
+      uint32_t len;
+      uint32_t own_lo;  // chunk-local columns [own_lo, len) are its own region (0-based)
+    };
+    std::vector<Chunk> chunks;
+    std::vector<uint32_t> first_chunk(tids.size() + 1, 0);
+    for (size_t i = 0; i < tids.size(); i++) {
+      const uint64_t T = dec[tids[i]].sym.size();
+      first_chunk[i] = (uint32_t)chunks.size();
+      for (uint64_t c = 0;; c++) {
+        const uint64_t start = c * S;
+        if (c > 0 && start + O >= T) break;  // nothing left that the previous chunk does not own
+        chunks.push_back(Chunk{tids[i], (uint32_t)start, (uint32_t)std::min<uint64_t>(S + O, T - start), (uint32_t)(c ? O : 0)});
+      }
+    }
+    first_chunk[tids.size()] = (uint32_t)chunks.size();
     std::string flat;
-    std::vector<uint64_t> off(tids.size() + 1, 0);
+    std::vector<uint64_t> off(chunks.size() + 1, 0);
     size_t total = 0;
-    for (uint32_t t : tids) total += dec[t].sym.size();
+    for (const Chunk& c : chunks) total += c.len;
     flat.resize(total);
     size_t at = 0;
-    for (size_t i = 0; i < tids.size(); i++) {
-      const Decoded& d = dec[tids[i]];
-      memcpy(&flat[at], d.src, d.sym.size());  // (ASCII: one byte per symbol)
-      at += d.sym.size();
+    for (size_t i = 0; i < chunks.size(); i++) {
+      memcpy(&flat[at], dec[chunks[i].tid].src + chunks[i].start, chunks[i].len);  // (ASCII: one byte per symbol)
+      at += chunks[i].len;
       off[i + 1] = at;
     }
+    StageTimer tm(100000);
     DbHolder holder;
     holder.db = db_create_owned(ctx, std::move(flat), std::move(off));
+    tm.lap("  windows: temp db");
     if (!holder.db) return SW_E_HIP;
     sw_db* db = holder.db;
+    st.chunks += chunks.size();
     for (uint32_t qid : set.second) {
       const Decoded& q = dec[qid];
       const uint32_t Q = (uint32_t)q.sym.size();
@@ -135,46 +161,62 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
       PersistPass pp;
       if ((rc = db_score_persist_locked(*L.c, L.c->ws, db, qp, sc, pp))) return rc;
       st.queries++;
+      if (tm.on) fprintf(stderr, "[sw_hip]   windows: score kernel %.3f ms (Q = %u)\n", L.c->stats.score_kernel_ms, Q);
+      tm.lap("  windows: score pass");
       const std::vector<ScoreUnit>& units = *pp.units;
       const std::vector<ScoreGroup>& groups = *pp.groups;
       std::vector<uint32_t> unit_of_elem(pp.n_elems, UINT32_MAX);
       for (uint32_t u = 0; u < units.size(); u++)
         for (uint32_t e = 0; e < units[u].count; e++) unit_of_elem[units[u].first_elem + e] = u;
-      std::vector<uint32_t> slot_of(tids.size(), UINT32_MAX);
-      for (size_t s = 0; s < pp.slot_target->size(); s++)
-        if ((*pp.slot_target)[s] != UINT32_MAX) slot_of[(*pp.slot_target)[s]] = (uint32_t)s;
+      std::vector<uint32_t> slot_of(chunks.size(), UINT32_MAX);  // chunk -> lane slot
+      for (size_t sl = 0; sl < pp.slot_target->size(); sl++)
+        if ((*pp.slot_target)[sl] != UINT32_MAX) slot_of[(*pp.slot_target)[sl]] = (uint32_t)sl;
       // ---- round 1: the windows that can hold the end cell
+      struct Win {
+        size_t pair;     // index into `pairs`
+        uint32_t chunk;  // database sequence
+        uint32_t unit;   // ticket of the work unit the window lies in
+        uint32_t col0;   // chunk-local columns left of the window
+        uint32_t cols;   // window width
+      };
       std::vector<Win> wins;
       std::vector<int32_t> want(pairs.size(), 0);
       for (size_t pi = 0; pi < pairs.size(); pi++) {
         const size_t k = pairs[pi];
         const uint32_t tl = (uint32_t)(std::lower_bound(tids.begin(), tids.end(), pair_t[k]) - tids.begin());
-        const uint32_t slot = slot_of[tl];
-        const uint32_t T = (uint32_t)dec[pair_t[k]].sym.size();
-        if (slot == UINT32_MAX) continue;
-        const int32_t s = pp.slot[slot];
-        if (s >= 32767) continue;  // (cannot happen: Q * match < 32767)
+        int32_t s = 0;
+        bool usable = true;
+        for (uint32_t c = first_chunk[tl]; c < first_chunk[tl + 1]; c++) {
+          if (slot_of[c] == UINT32_MAX || pp.slot[slot_of[c]] >= 32767) usable = false;  // (cannot happen: Q * match < 32767)
+          else s = std::max(s, pp.slot[slot_of[c]]);
+        }
+        if (!usable) continue;
         want[pi] = s;
-        if (s <= 0) {              // no hit: nothing to trace
+        if (s <= 0) {  // no hit: nothing to trace
           po[k] = PairOut{};
           handled[k] = 1;
           st.pairs++;
           continue;
         }
-        const ScoreGroup& G = groups[slot / kGroupTargets];
-        const uint32_t lane = slot % 64, shift = 16 * ((slot % kGroupTargets) / 64);
-        const uint32_t nst = (T + kScoreR - 1) / kScoreR;
-        uint32_t last_unit = UINT32_MAX;
-        for (uint32_t st_ = 0; st_ < nst; st_++) {
-          const uint32_t e = G.strip_base + st_;
-          if ((int32_t)(int16_t)((pp.strip_best[(size_t)e * 64 + lane] >> shift) & 0xffffu) != s) continue;
-          const uint32_t u = unit_of_elem[e];
-          const uint32_t first = std::max(units[u].first_elem, G.strip_base);
-          const uint32_t col0 = (first - G.strip_base) * kScoreR;
-          const uint32_t cols = std::min(T, (st_ + 1) * kScoreR) - col0;
-          if (u == last_unit) wins.back().cols = cols;  // a later strip of the same unit: widen
-          else wins.push_back(Win{pi, u, col0, cols});
-          last_unit = u;
+        for (uint32_t c = first_chunk[tl]; c < first_chunk[tl + 1]; c++) {
+          const uint32_t slot = slot_of[c];
+          if (pp.slot[slot] != s) continue;
+          const Chunk& C = chunks[c];
+          const ScoreGroup& G = groups[slot / kGroupTargets];
+          const uint32_t lane = slot % 64, shift = 16 * ((slot % kGroupTargets) / 64);
+          const uint32_t nst = (C.len + kScoreR - 1) / kScoreR;
+          uint32_t last_unit = UINT32_MAX;
+          for (uint32_t st_ = C.own_lo / kScoreR; st_ < nst; st_++) {  // strips that reach into the own region
+            const uint32_t e = G.strip_base + st_;
+            if ((int32_t)(int16_t)((pp.strip_best[(size_t)e * 64 + lane] >> shift) & 0xffffu) != s) continue;
+            const uint32_t u = unit_of_elem[e];
+            const uint32_t first = std::max(units[u].first_elem, G.strip_base);
+            const uint32_t col0 = (first - G.strip_base) * kScoreR;
+            const uint32_t cols = std::min(C.len, (st_ + 1) * kScoreR) - col0;
+            if (u == last_unit) wins.back().cols = cols;  // a later strip of the same unit: widen
+            else wins.push_back(Win{pi, c, u, col0, cols});
+            last_unit = u;
+          }
         }
       }
       // ---- rounds: fill + walk the windows; a path that leaves a window on its left continues in the next round
@@ -188,26 +230,25 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
       };
       std::vector<Trace> tr(pairs.size());
       bool first_round = true;
+      uint32_t round_no = 0;
       while (!wins.empty()) {
         std::vector<PairSpec> specs(wins.size());
         for (size_t w = 0; w < wins.size(); w++) {
           const Win& W = wins[w];
-          const size_t k = pairs[W.pair];
-          const Decoded& t = dec[pair_t[k]];
-          const uint32_t tl = (uint32_t)(std::lower_bound(tids.begin(), tids.end(), pair_t[k]) - tids.begin());
-          const uint32_t slot = slot_of[tl];
+          const Chunk& C = chunks[W.chunk];
+          const Decoded& t = dec[C.tid];
+          const uint32_t slot = slot_of[W.chunk];
           const ScoreGroup& G = groups[slot / kGroupTargets];
           PairSpec& sp = specs[w];
           sp.q = q.sym.data();
           sp.Q = first_round ? Q : tr[W.pair].res_x;  // (a continuation needs the rows above the resume point only)
-          sp.t = t.sym.data() + W.col0;
+          sp.t = t.sym.data() + C.start + W.col0;
           sp.T = W.cols;
           sp.path = SW_PATH_LOW_MEMORY;
-          sp.col0 = W.col0;
+          sp.col0 = C.start + W.col0;  // global: the discovery-order key and the column limits count from the target's start
           sp.Qfull = Q;
           sp.Tfull = (uint32_t)t.sym.size();
-          const bool has_left = W.col0 > 0;
-          if (has_left) {
+          if (W.col0 > 0) {
             if (units[W.unit].dep == UINT32_MAX || std::max(units[W.unit].first_elem, G.strip_base) != units[W.unit].first_elem)
               return fail(SW_E_HIP, "internal: window without a boundary column");
             sp.left = pp.d_ring + (size_t)units[W.unit].dep * pp.ring_stride + slot % 64;
@@ -229,7 +270,9 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
         for (size_t w = 0; w < wins.size(); w++) {
           const size_t pi = wins[w].pair;
           if (first_round) {
-            if (outs[w].score != want[pi]) continue;  // the maximum of this window is elsewhere (cannot happen)
+            if (outs[w].score != want[pi]) continue;  // this window's own maximum is lower: the strip's lay in other rows
+            // a maximal cell in the overlap part of a chunk belongs to the chunk before (which reports it too)
+            if (outs[w].bj + wins[w].col0 <= chunks[wins[w].chunk].own_lo) continue;
             if (chosen[pi] == SIZE_MAX || outs[w].key < outs[chosen[pi]].key) chosen[pi] = w;
           } else {
             chosen[pi] = w;
@@ -246,19 +289,27 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
           const PairOut& o = outs[w];
           if (first_round) {
             T_.bx = o.bx;
-            T_.bj = o.bj + wins[w].col0;
+            T_.bj = o.bj + wins[w].col0 + chunks[wins[w].chunk].start;
             T_.key = o.key;
           }
           T_.ops.insert(T_.ops.end(), ops_arena.begin() + (ptrdiff_t)o.ops_off, ops_arena.begin() + (ptrdiff_t)(o.ops_off + o.nops));
-          if (o.end_H > 0 && o.end_j == 0 && wins[w].col0 > 0 && o.end_x >= 1) {
-            // the path crossed the window's left edge: resume at (end_x, last column of the unit to the left)
-            const size_t k = pairs[pi];
-            const uint32_t tl = (uint32_t)(std::lower_bound(tids.begin(), tids.end(), pair_t[k]) - tids.begin());
-            const ScoreGroup& G = groups[slot_of[tl] / kGroupTargets];
-            const uint32_t up = units[wins[w].unit].dep;
+          if (o.end_H > 0 && o.end_j == 0 && o.end_x >= 1 && (wins[w].col0 > 0 || chunks[wins[w].chunk].start > 0)) {
+            if (wins[w].col0 == 0) {  // the path would leave its chunk: impossible by the overlap bound -- do not guess
+              T_.failed = true;
+              st.chunk_escapes++;
+              continue;
+            }
+            // the path crossed the window's left edge: resume at (end_x, last column of the unit to the left).  The
+            // next window spans 2, 4, 8, ... units (every unit boundary has its column stored, so any unit can be
+            // the entry): a long alignment costs a logarithmic number of rounds, a short one few cells.
+            const ScoreGroup& G = groups[slot_of[wins[w].chunk] / kGroupTargets];
+            uint32_t up = units[wins[w].unit].dep;
+            for (uint32_t more = (1u << std::min<uint32_t>(round_no + 1, 4)) - 1;
+                 more > 0 && units[up].first_elem > G.strip_base && units[up].dep != UINT32_MAX; more--)
+              up = units[up].dep;
             const uint32_t first = std::max(units[up].first_elem, G.strip_base);
             const uint32_t col0 = (first - G.strip_base) * kScoreR;
-            next.push_back(Win{pi, up, col0, wins[w].col0 - col0});
+            next.push_back(Win{pi, wins[w].chunk, up, col0, wins[w].col0 - col0});
             T_.done = false;
             T_.res_H = o.end_H;
             T_.res_x = o.end_x;
@@ -268,7 +319,9 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
         }
         wins.swap(next);
         first_round = false;
+        round_no++;
         st.rounds++;
+        tm.lap("  windows: round");
       }
       for (size_t pi = 0; pi < pairs.size(); pi++) {
         const size_t k = pairs[pi];
@@ -291,7 +344,7 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
   return SW_OK;
 }
 
-extern "C" void sw_hip_package_stats(uint64_t out[5]) {
+extern "C" void sw_hip_package_stats(uint64_t out[7]) {
   if (!out) return;
   const PackageStats s = g_package_stats;
   out[0] = s.pairs;
@@ -299,4 +352,6 @@ extern "C" void sw_hip_package_stats(uint64_t out[5]) {
   out[2] = s.windows;
   out[3] = s.rounds;
   out[4] = s.window_cells;
+  out[5] = s.chunks;
+  out[6] = s.chunk_escapes;
 }

@@ -203,11 +203,13 @@ int sw_node_last_stats(const sw_node_db *db, int shard, struct sw_kernel_stats *
  * the oracle's clean model without a GPU. */
 int sw_hip_path_params(int path, uint64_t q_len, uint64_t t_len, uint32_t out[4]);
 /* Counters of the last sw_align_batch / sw_execute_work call that took the work-package fast path (long ACGT
- * targets: score pass by the packed inter-task kernel, end cell and traceback inside windows of at most 256 target
- * columns): out[0] = pairs it answered, out[1] = score passes (queries), out[2] = windows filled by the exact
- * kernel, out[3] = rounds (1 + continuations to the left), out[4] = cells of those windows.  All zero if the last
- * call did not take it. */
-void sw_hip_package_stats(uint64_t out[5]);
+ * targets: score pass by the packed inter-task kernel over overlapping chunks of the targets, end cell and traceback
+ * inside windows of at most 256 target columns): out[0] = pairs it answered, out[1] = score passes (queries),
+ * out[2] = windows filled by the exact kernel, out[3] = rounds (1 + continuations to the left), out[4] = cells of
+ * those windows, out[5] = chunks the targets were cut into, out[6] = tracebacks that tried to leave their chunk
+ * (must be 0: the overlap bound; such a pair is redone by the whole-matrix path).  All zero if the last call did
+ * not take it. */
+void sw_hip_package_stats(uint64_t out[7]);
 /* sizeof() of the additive ABI structs as the library was compiled: 0 = sw_kernel_stats, 1 = sw_hit,
  * 2 = sw_alignment_detail, 3 = sw_work_package, 4 = sw_work_pair (0 for an unknown index).  Lets a binding written
  * in another language (ctypes, cgo) assert that its mirror of a struct has not fallen behind the header. */

@@ -72,6 +72,32 @@ def batch_case(name, qlen, lens, nq=1):
     print(json.dumps({"case": name, "pairs": len(Qs), "cells": cells, "ms": round(best * 1e3, 2), "gcups": round(cells / best / 1e9, 1),
                       "free_ms": round(tfree * 1e3, 2), "kernels_ms": round(kms, 3), "kernel_gcups": round(cells / kms / 1e6, 1)}), flush=True)
 
+def package_case(name, nq, qmin, qmax, nt, tmin, tmax):
+    """ExecuteWork on the reference's own synthetic distribution (utils/generate_synthetic_data.py defaults:
+    10 queries of 200-1000 nt, 800 targets of 10-200 kb): every pair of the cross product through sw_align_batch."""
+    qf, qo = bridge.synth(101, nq, qmin, qmax)
+    tf, to = bridge.synth(102, nt, tmin, tmax)
+    qs = [qf[int(qo[i]):int(qo[i + 1])].tobytes() for i in range(nq)]
+    ts = [tf[int(to[i]):int(to[i + 1])].tobytes() for i in range(nt)]
+    import ctypes as C
+    L = bridge.lib()
+    qb = [C.create_string_buffer(x) for x in qs]; tb = [C.create_string_buffer(x) for x in ts]
+    n = nq * nt
+    qa = (C.c_char_p * n)(*[C.cast(qb[i // nt], C.c_char_p) for i in range(n)])
+    ta = (C.c_char_p * n)(*[C.cast(tb[i % nt], C.c_char_p) for i in range(n)])
+    sc = dlsa_amd.AlignmentScore(2, -1, -1)
+    cells = float(sum(len(q) for q in qs)) * float(sum(len(t) for t in ts))
+    best = 1e9
+    for _ in range(2):
+        out = (C.POINTER(bridge.CResult) * n)()
+        t0 = time.perf_counter(); rc = L.sw_align_batch(qa, ta, n, sc.c(), 0, out); dt = time.perf_counter() - t0
+        assert rc == 0, bridge.last_error()
+        chk = sum(int(out[i].contents.score) for i in range(0, n, max(1, n // 50)))
+        for i in range(n): L.free_alignment_result(out[i])
+        best = min(best, dt)
+    print(json.dumps({"case": name, "pairs": n, "cells": cells, "ms": round(best * 1e3, 2), "gcups": round(cells / best / 1e9, 1),
+                      "package": bridge.package_stats(), "check": chk}), flush=True)
+
 which = sys.argv[1:]
 rng = np.random.default_rng(3)
 if "c1" in which: db_case("C1 1kb x 1000x[900,1100]", 1000, rng.integers(900, 1101, size=1000))
@@ -97,3 +123,5 @@ if "b5" in which: batch_case("ExecuteWork 150 x 100000x150", 150, np.full(100000
 if "strips" in which:
     for Q in (256, 1024, 2560, 25600):
         pair_case(f"strip timing Q={Q}", Q, 100000)
+if "b3" in which: package_case("ExecuteWork generate_synthetic_data defaults: 10 x [200,1000] vs 800 x [10k,200k]", 10, 200, 1000, 800, 10000, 200000)
+if "b3s" in which: package_case("ExecuteWork 10 x [200,1000] vs 100 x [10k,200k]", 10, 200, 1000, 100, 10000, 200000)

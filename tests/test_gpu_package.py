@@ -48,7 +48,8 @@ def test_package_of_long_targets_matches_the_oracle(oracle):
     ts = targets * len(queries)
     res = bridge.align_batch(qs, ts, s, 0)
     st = bridge.package_stats()
-    assert st["pairs"] == len(qs) and st["queries"] == len(queries)
+    assert st["pairs"] == len(qs) and st["queries"] == len(queries) and st["chunk_escapes"] == 0
+    assert st["chunks"] > len(targets)                       # the 60 kb target was cut into overlapping chunks
     assert st["rounds"] > len(queries)                       # some traceback continued to the left
     total = sum(len(q) * len(t) for q, t in zip(qs, ts))
     assert st["window_cells"] < 0.25 * total                 # the exact kernel saw a fraction of the matrix
@@ -74,7 +75,7 @@ def test_package_mixed_with_ineligible_pairs_and_other_scorings(oracle):
         ts = targets * 2
         res = bridge.align_batch(qs, ts, s, 0)
         st = bridge.package_stats()
-        assert st["pairs"] == 2 * len(long_t), st
+        assert st["pairs"] == 2 * len(long_t) and st["chunk_escapes"] == 0 and st["chunks"] > len(long_t), st
         for r, q, t in zip(res, qs, ts):
             _check(oracle, r, q, t, sc)
     # the worker's entry point (sw_execute_work): same path underneath
