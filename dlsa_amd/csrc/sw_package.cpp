@@ -104,8 +104,15 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
     uint32_t Qmax = 0;
     for (uint32_t qid : set.second) Qmax = std::max<uint32_t>(Qmax, (uint32_t)dec[qid].sym.size());
     const uint64_t O = (uint64_t)Qmax + (uint64_t)Qmax * (uint64_t)sc.match / (uint64_t)(-sc.gap) + 1;
+    // Chunk stride S: 2 O (half as much overlap as payload) when the set is large; a set with few residues gets
+    // shorter chunks, down to O / 2, so that it still fills the 128 lanes of a few groups -- a wave costs the same
+    // whether 21 or 128 of its lanes hold a chunk (swept on the 10 x 800 package: 1 O .. 5 O within 15 %, smaller is
+    // better because more groups mean more independent chains)
+    uint64_t set_residues = 0;
+    for (uint32_t t : tids) set_residues += dec[t].sym.size();
     static const double chunk_mult = getenv("SW_HIP_CHUNK_MULT") ? atof(getenv("SW_HIP_CHUNK_MULT")) : 2.0;  // experiments
-    const uint64_t S = std::max<uint64_t>((uint64_t)(chunk_mult * (double)O), 4096);
+    uint64_t S = (uint64_t)(chunk_mult * (double)O);
+    S = std::max<uint64_t>(std::min<uint64_t>(S, set_residues / 256), std::max<uint64_t>(O / 2, 1024));
     struct Chunk {
       uint32_t tid;     // index into dec
       uint32_t start;   // first target column of the chunk (0-based)
