@@ -86,7 +86,9 @@ __device__ __forceinline__ uint32_t push_dir_bits(uint32_t acc, int a1, int b1, 
 // started, rows >= Q of the last strip) need no masking there, because with sentinel symbols that never match
 // they evaluate to 0 from zero inputs, and phantom rows below the matrix only see values strictly smaller than
 // a real cell's, so they never win the maximum.  MASK = true handles the right edge and odd scorings.
-template <int RPL, bool DIRS, bool MASK>
+// WIN = true: the pair is a window with a known boundary column on its left (P.left); compiled separately so that
+// the whole-matrix path keeps exactly its registers and instructions.
+template <int RPL, bool DIRS, bool MASK, bool WIN>
 __device__ __forceinline__ void exact_steps16(const uint32_t (&qs)[RPL], const bool (&valid)[RPL], int (&h)[RPL],
                                               int (&bestv)[RPL], uint32_t (&bestj)[RPL], uint32_t (&acc)[RPL],
                                               int& top_prev, int& last_out, int& tcur, int (&hist)[16], int& jv,
@@ -119,8 +121,13 @@ __device__ __forceinline__ void exact_steps16(const uint32_t (&qs)[RPL], const b
         // column 0 of a window holds the known boundary column H(x, col0) (zero for a whole matrix): every lane
         // passes through jv == 0 one step before its first real column, which is what puts the boundary into
         // h[] (the next step's `left`), into the row above's diagonal and into the lane below's top_prev
-        hn = act ? hn : (jv == 0 ? leftv[r] : 0);
-        hb = act ? hn : 0;
+        if (WIN) {
+          hn = act ? hn : (jv == 0 ? leftv[r] : 0);
+          hb = act ? hn : 0;
+        } else {
+          hn = act ? hn : 0;
+          hb = hn;
+        }
       }
       if (DIRS) {
         // bit 1: up >= left; bit 0: the diagonal wins (for H > 0: H == diag + s  <=>  diag + s >= max(up, left) + gap)
@@ -139,7 +146,7 @@ __device__ __forceinline__ void exact_steps16(const uint32_t (&qs)[RPL], const b
   }
 }
 
-template <int RPL, bool DIRS>
+template <int RPL, bool DIRS, bool WIN>
 __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork& W, uint32_t strip, int match,
                                             int miss, int gap, int& gbv, uint64_t& gkey) {
   const int lane = threadIdx.x & 63;
@@ -165,7 +172,7 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
     uint32_t i = ibase + r;
     valid[r] = i < Q;
     qs[r] = valid[r] ? P.q[i] : 0x10000u;  // never equals a u16 symbol
-    leftv[r] = (P.left && valid[r]) ? (int)((P.left[(size_t)i * 64] >> P.left_shift) & 0xffffu) : 0;
+    leftv[r] = (WIN && valid[r]) ? (int)((P.left[(size_t)i * 64] >> P.left_shift) & 0xffffu) : 0;
     h[r] = leftv[r];  // lane 0 starts at column 1 and never passes through column 0: its `left` is the boundary now
     bestv[r] = 0;
     bestj[r] = 0;
@@ -175,7 +182,7 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
   const uint32_t lim0 = row1_lane ? P.T0 : P.Tlim;  // column limit of this lane's row r == 0
   // ... and so is its first diagonal: H(row above lane 0's first row, col0).  (The other lanes get both through the
   // wavefront: every lane above them is forced to the boundary column when it passes column 0.)
-  int top_prev = (P.left && lane == 0 && ibase > 0) ? (int)((P.left[(size_t)(ibase - 1) * 64] >> P.left_shift) & 0xffffu) : 0;
+  int top_prev = (WIN && lane == 0 && ibase > 0) ? (int)((P.left[(size_t)(ibase - 1) * 64] >> P.left_shift) & 0xffffu) : 0;
   int last_out = h[RPL - 1];  // lane 1's first diagonal is lane 0's last row at column 0: the boundary again
   int hist[16];
   int tcur = 0x20000;
@@ -209,11 +216,11 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
     }
     // (a window with a boundary column runs masked while any lane is still at or left of column 0: lane 63
     // reaches column 1 at step 63)
-    if (plain && g * 16 + 16 <= mincol && !(P.left && g < 4))
-      exact_steps16<RPL, DIRS, false>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
+    if (plain && g * 16 + 16 <= mincol && !(WIN && g < 4))
+      exact_steps16<RPL, DIRS, false, WIN>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
                                  match, miss, gap, lim0, P.Tlim, leftv);
     else
-      exact_steps16<RPL, DIRS, true>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
+      exact_steps16<RPL, DIRS, true, WIN>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
                                 match, miss, gap, lim0, P.Tlim, leftv);
     if (DIRS) {
       uint32_t* w = P.dirs + ((size_t)(strip * P.nkb + g) * RPL) * 64 + lane;
@@ -279,10 +286,14 @@ __global__ void __launch_bounds__(64) sw_exact_kernel(ExactWork W, int match, in
   int gbv = 0;
   uint64_t gkey = ~0ull;
   if (strip < exact_nstrips(P.Q, RPL) && maxcol > 0) {
-    if (P.dirs)
-      exact_strip<RPL, true>(P, W, strip, match, miss, gap, gbv, gkey);
-    else
-      exact_strip<RPL, false>(P, W, strip, match, miss, gap, gbv, gkey);
+    if (P.left) {  // a window entered through a stored boundary column (always with direction bits)
+      if (P.dirs) exact_strip<RPL, true, true>(P, W, strip, match, miss, gap, gbv, gkey);
+      else exact_strip<RPL, false, true>(P, W, strip, match, miss, gap, gbv, gkey);
+    } else if (P.dirs) {
+      exact_strip<RPL, true, false>(P, W, strip, match, miss, gap, gbv, gkey);
+    } else {
+      exact_strip<RPL, false, false>(P, W, strip, match, miss, gap, gbv, gkey);
+    }
   }
   wave_best(gbv, gkey);
   // The last strip of a pair to finish combines the per-strip records (threadfence reduction).
