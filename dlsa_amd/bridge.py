@@ -51,7 +51,8 @@ class CWorkPackage(C.Structure):  # include/sw_worker.h struct sw_work_package
 class CAlignmentDetail(C.Structure):  # include/sw_worker.h struct sw_alignment_detail
     _fields_ = [("query", C.c_uint32), ("target", C.c_uint32), ("query_alignment", C.c_void_p),
                 ("target_alignment", C.c_void_p), ("length", C.c_int64), ("score", C.c_int64),
-                ("max_x", C.c_int64), ("max_y", C.c_int64), ("score32", C.c_int32), ("entry", C.c_int32)]
+                ("max_x", C.c_int64), ("max_y", C.c_int64), ("score32", C.c_int32), ("entry", C.c_int32),
+                ("owner_", C.c_void_p)]
 
 
 class CStats(C.Structure):  # include/sw_hip.h struct sw_kernel_stats

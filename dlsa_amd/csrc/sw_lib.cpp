@@ -545,12 +545,23 @@ int swhip::run_exact(Context& c, Workspace& ws, const PairSpec* specs, size_t n,
 
 namespace {
 // ---- Result boxes ------------------------------------------------------------------------------------------
+// A batch (sw_align_batch / sw_execute_work: 10^5 results at a time) allocates ONE block, a slab, for all its boxes
+// and strings instead of three heap blocks per result; the slab counts its live parts (a box and each of its two
+// strings) and is freed with the last one, so free_alignment_result / free_c_string keep their one-call-per-object
+// contract.  A result of the one-pair entry points has no slab.
+struct Slab {
+  std::atomic<uint64_t> refs;
+};
 struct ResultBox {
   Result r;
   int32_t score32;
   uint32_t magic;
+  Slab* slab;  // nullptr: box and strings are heap blocks of their own
 };
 constexpr uint32_t kMagic = 0x53574850u;  // "SWHP"
+void slab_release(Slab* s, uint64_t n) {
+  if (s->refs.fetch_sub(n, std::memory_order_acq_rel) == n) free(s);
+}
 // Result strings carry a 16-byte header in front of the characters: which Result (if any) still owns them.  That
 // is what lets free_c_string() be called on either string of a Result before free_alignment_result()
 // (SURVEY.md 8b "Ownership") without a global registry -- a work package returns 10^5 results at a time.
@@ -558,7 +569,8 @@ struct StrHdr {
   ResultBox* owner;  // nullptr: a stand-alone string (sw_hit)
   uint64_t magic;
 };
-constexpr uint64_t kStrMagic = 0x5357485053545231ull;  // "SWHPSTR1"
+constexpr uint64_t kStrMagic = 0x5357485053545231ull;      // "SWHPSTR1": a heap block of its own
+constexpr uint64_t kStrMagicSlab = 0x5357485053545232ull;  // "SWHPSTR2": lives in its owner's slab
 }  // namespace
 char* swhip::str_alloc(size_t n) {
   StrHdr* h = (StrHdr*)malloc(sizeof(StrHdr) + n + 1);
@@ -654,6 +666,7 @@ bool swhip::build_alignment(const Decoded& q, const Decoded& t, const PairOut& o
 
 namespace {
 // takes ownership of qa / ta (from str_alloc)
+void box_fill(ResultBox* b, char* qa, char* ta, int path, const PairOut& o);
 ResultBox* box_result(char* qa, char* ta, int path, const PairOut& o) {
   ResultBox* b = (ResultBox*)calloc(1, sizeof(ResultBox));
   if (!b) {
@@ -661,6 +674,10 @@ ResultBox* box_result(char* qa, char* ta, int path, const PairOut& o) {
     str_free(ta);
     return nullptr;
   }
+  box_fill(b, qa, ta, path, o);
+  return b;
+}
+void box_fill(ResultBox* b, char* qa, char* ta, int path, const PairOut& o) {
   b->r.query_ptr = qa;
   b->r.target_ptr = ta;
   ((StrHdr*)qa - 1)->owner = b;
@@ -677,7 +694,6 @@ ResultBox* box_result(char* qa, char* ta, int path, const PairOut& o) {
     b->r.max_x = (uint64_t)o.bx - 1;
     b->r.max_y = (uint64_t)o.bj - 1;
   }
-  return b;
 }
 }  // namespace
 Scoring swhip::to_scoring(AlignmentScores s) {
@@ -801,16 +817,69 @@ int align_many(const char* const* queries, const char* const* targets, size_t n,
     }
   }
   tm.lap("run_exact");
-  parallel_ranges(specs.size(), arena.size() * 4, [&](size_t lo, size_t hi) {
+  // One slab for the whole batch: [Slab | ResultBox x pairs | per pair: StrHdr + query alignment + NUL, StrHdr +
+  // target alignment + NUL].  ASCII pairs (the normal case) know their string lengths up front (= the number of
+  // traceback ops); a pair with non-ASCII symbols re-encodes to UTF-8 and keeps heap strings of its own.
+  auto round8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+  std::vector<size_t> str_off(specs.size() + 1, 0);
+  const size_t boxes_off = round8(sizeof(Slab));
+  size_t bytes = boxes_off + specs.size() * sizeof(ResultBox);
+  for (size_t k = 0; k < specs.size(); k++) {
+    const size_t i = idx[k];
+    str_off[k] = bytes;
+    if (dec[qi[i]].ascii && dec[ti[i]].ascii) bytes += 2 * (sizeof(StrHdr) + round8((size_t)po[k].nops + 1));
+  }
+  str_off[specs.size()] = bytes;
+  Slab* slab = (Slab*)malloc(bytes);
+  if (!slab) return fail(SW_E_NOMEM, "out of host memory");
+  new (&slab->refs) std::atomic<uint64_t>(0);
+  ResultBox* boxes = (ResultBox*)((char*)slab + boxes_off);
+  std::atomic<uint64_t> live{0};
+  parallel_ranges(specs.size(), arena.size() * 4 + specs.size() * 64, [&](size_t lo, size_t hi) {
+    uint64_t mine = 0;
     for (size_t k = lo; k < hi; k++) {
       const size_t i = idx[k];
-      char *qa = nullptr, *ta = nullptr;
-      size_t qlen = 0;
-      if (!build_alignment(dec[qi[i]], dec[ti[i]], po[k], arena.data() + po[k].ops_off, &qa, &ta, &qlen)) continue;
-      ResultBox* b = box_result(qa, ta, path, po[k]);
-      out[i] = b ? &b->r : nullptr;
+      ResultBox* b = boxes + k;
+      memset(b, 0, sizeof(ResultBox));
+      const Decoded &q = dec[qi[i]], &t = dec[ti[i]];
+      const PairOut& o = po[k];
+      const uint8_t* ops = arena.data() + o.ops_off;
+      if (q.ascii && t.ascii) {
+        const size_t each = sizeof(StrHdr) + round8((size_t)o.nops + 1);
+        StrHdr* hq = (StrHdr*)((char*)slab + str_off[k]);
+        StrHdr* ht = (StrHdr*)((char*)slab + str_off[k] + each);
+        hq->magic = ht->magic = kStrMagicSlab;
+        char *qa = (char*)(hq + 1), *ta = (char*)(ht + 1);
+        uint32_t nx = 0, nj = 0;
+        for (uint32_t c = 0; c < o.nops; c++) {
+          nx += ops[c] != 2;
+          nj += ops[c] != 1;
+        }
+        uint32_t cx = o.bx - nx, cj = o.bj - nj;  // 0-based index of the first aligned symbol
+        size_t w = 0;
+        for (uint32_t c = o.nops; c-- > 0; w++) {
+          const uint8_t op = ops[c];
+          qa[w] = op == 2 ? '-' : q.src[cx++];
+          ta[w] = op == 1 ? '-' : t.src[cj++];
+        }
+        qa[w] = ta[w] = 0;
+        b->slab = slab;
+        box_fill(b, qa, ta, path, o);
+        mine += 3;
+      } else {
+        char *qa = nullptr, *ta = nullptr;
+        size_t qlen = 0;
+        if (!build_alignment(q, t, o, ops, &qa, &ta, &qlen)) continue;  // (out of memory: the pair reads as failed)
+        b->slab = slab;
+        box_fill(b, qa, ta, path, o);
+        mine += 1;  // the box only: its strings are heap blocks
+      }
+      out[i] = &b->r;
     }
+    live.fetch_add(mine);
   });
+  if (live.load() == 0) free(slab);
+  else slab->refs.store(live.load(), std::memory_order_release);
   tm.lap("strings");
   return SW_OK;
 }
@@ -949,24 +1018,40 @@ void free_alignment_result(Result* result) {
   if (!result) return;
   ResultBox* b = (ResultBox*)result;
   if (b->magic != kMagic) return;  // not ours (or already freed): leave it alone
-  str_free(b->r.query_ptr);        // (a string handed to free_c_string earlier has been detached: nullptr)
-  str_free(b->r.target_ptr);
   b->magic = 0;
-  free(b);
+  // (a string handed to free_c_string earlier has been detached: nullptr)
+  uint64_t parts = 1;
+  for (char* sp : {b->r.query_ptr, b->r.target_ptr}) {
+    if (!sp) continue;
+    StrHdr* h = (StrHdr*)sp - 1;
+    if (h->magic == kStrMagicSlab) {
+      h->magic = 0;
+      parts++;
+    } else {
+      str_free(sp);
+    }
+  }
+  if (b->slab) slab_release(b->slab, parts);
+  else free(b);
 }
 
 void free_c_string(char* str) {
   if (!str) return;
   StrHdr* h = (StrHdr*)str - 1;
-  if (h->magic != kStrMagic) {  // not one of ours: the reference would hand it to CString::from_raw all the same
-    free(str);
-    return;
-  }
-  if (ResultBox* b = h->owner) {  // detach from its Result so free_alignment_result will not free it again
+  // Only strings this library returned may be passed (include/sw.h).  Anything else is left alone: looking in front
+  // of a foreign pointer is already out of bounds, freeing it would be worse.
+  if (h->magic != kStrMagic && h->magic != kStrMagicSlab) return;
+  ResultBox* b = h->owner;
+  if (b) {  // detach from its Result so free_alignment_result will not free it again
     if (b->r.query_ptr == str) b->r.query_ptr = nullptr;
     if (b->r.target_ptr == str) b->r.target_ptr = nullptr;
   }
-  str_free(str);
+  if (h->magic == kStrMagicSlab) {
+    h->magic = 0;
+    if (b && b->slab) slab_release(b->slab, 1);
+  } else {
+    str_free(str);
+  }
 }
 
 // ================================================================================================

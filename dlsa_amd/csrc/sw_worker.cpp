@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <memory>
 #include <string>
@@ -31,9 +32,12 @@ char* dup_cstr(const char* s) {
 }
 
 // convertResultToGoResult (worker_rust_bridge.go:131-139) + the packing of worker_impl.go:136-155
+// The detail takes the Result over: its strings are used in place (a package returns 10^5 of them; copying each
+// twice and freeing the originals was a third of the call).
 bool fill_detail(sw_alignment_detail& d, Result* r, int entry) {
-  d.query_alignment = dup_cstr(r->query_ptr ? r->query_ptr : "");
-  d.target_alignment = dup_cstr(r->target_ptr ? r->target_ptr : "");
+  d.query_alignment = r->query_ptr;
+  d.target_alignment = r->target_ptr;
+  d.owner_ = r;
   if (!d.query_alignment || !d.target_alignment) return false;
   d.length = (int64_t)strlen(d.query_alignment);  // Go: len(qRes), bytes
   d.score = (int64_t)r->score;                    // int(uint16)
@@ -95,8 +99,10 @@ static int execute_work(const sw_work_package* work, sw_alignment_detail* out, b
         failed.push_back(todo[k]);
         continue;
       }
-      if (!nomem && !fill_detail(out[todo[k]], res[k], chain[level])) nomem = true;
-      free_alignment_result(res[k]);
+      if (nomem || !fill_detail(out[todo[k]], res[k], chain[level])) {
+        nomem = true;
+        if (!out[todo[k]].owner_) free_alignment_result(res[k]);
+      }
     }
     if (nomem) {
       sw_alignment_details_free(out, n);
@@ -109,7 +115,8 @@ static int execute_work(const sw_work_package* work, sw_alignment_detail* out, b
     out[i].query_alignment = dup_cstr("");
     out[i].target_alignment = dup_cstr("");
   }
-  return SW_OK;
+  // every pair has a record; the count of pairs nothing could align is the (positive) return value
+  return SW_W_FAILED_PAIRS + (int)std::min<size_t>(todo.size(), 0x7fffffff);
 }
 
 int sw_execute_work(const sw_work_package* work, sw_alignment_detail* out) {
@@ -126,9 +133,14 @@ int sw_execute_work(const sw_work_package* work, sw_alignment_detail* out) {
 void sw_alignment_details_free(sw_alignment_detail* d, uint64_t n) {
   if (!d) return;
   for (uint64_t i = 0; i < n; i++) {
-    free(d[i].query_alignment);
-    free(d[i].target_alignment);
+    if (d[i].owner_) {
+      free_alignment_result((Result*)d[i].owner_);  // the strings are the Result's
+    } else {
+      free(d[i].query_alignment);
+      free(d[i].target_alignment);
+    }
     d[i].query_alignment = d[i].target_alignment = nullptr;
+    d[i].owner_ = nullptr;
   }
 }
 

@@ -107,8 +107,9 @@ class Worker:
         pkg = bridge.CWorkPackage(seqs, len(ids), pairs, n, work.match_score, work.mismatch_penalty, work.gap_penalty)
         out = (bridge.CAlignmentDetail * n)()
         rc = L.sw_execute_work(C.byref(pkg), out)
-        if rc != 0:
+        if rc < 0:  # (rc > 0: that many pairs failed on every entry point -- entry == -1 below)
             raise SwHipError(f"sw_execute_work failed ({rc}): {bridge.last_error()}")
+        self.failed_pairs = rc
         res = []
         for i, comb in enumerate(queries):
             d = out[i]

@@ -75,7 +75,9 @@ struct Result *find_alignment_sequential(char *query, char *target, struct Align
 void free_alignment_result(struct Result *result);
 
 /* replaces rust/src/bindings.rs:242-249 (wrapped at worker_rust_bridge.go:147-149, never invoked).  NULL
- * is accepted.  May be called on either string of a Result before free_alignment_result(). */
+ * is accepted.  May be called on either string of a Result before free_alignment_result().  Only pointers this
+ * library returned may be passed to the two free functions (strings of a Result or of a sw_hit); a pointer that
+ * does not carry the library's marker is left untouched. */
 void free_c_string(char *str);
 
 #ifdef __cplusplus

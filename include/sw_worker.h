@@ -50,7 +50,13 @@ struct sw_alignment_detail {
   int32_t score32;         /* additive: the un-truncated score (sw_result_score32) */
   int32_t entry;           /* additive: which entry point answered -- SW_PATH_LOW_MEMORY / _SIMD / _STRAIGHT
                               (the fallback chain of worker_impl.go:170-202), -1 if all three failed */
+  void *owner_;            /* internal: the library's Result the two strings belong to (they are not copied);
+                              released by sw_alignment_details_free */
 };
+/* Return value of sw_execute_work when every pair was computed but `n` of them failed on all three entry points
+ * (out[i].entry == -1, empty strings): SW_W_FAILED_PAIRS + n > 0.  The reference dereferences nil at that point
+ * (worker_impl.go:136); a caller should log or skip those pairs rather than post a score-0 alignment. */
+#define SW_W_FAILED_PAIRS 0
 /* What Worker.ExecuteWork (worker_impl.go:108-168) computes for its pair list, in ONE GPU submission per
  * fallback level instead of one cgo call per pair: out[i] is the AlignmentDetail of pairs[i], bit-identical
  * to the reference's (same entry-point order: find_alignment_low_memory, then find_alignment_simd for the

@@ -98,6 +98,31 @@ def package_case(name, nq, qmin, qmax, nt, tmin, tmax):
     print(json.dumps({"case": name, "pairs": n, "cells": cells, "ms": round(best * 1e3, 2), "gcups": round(cells / best / 1e9, 1),
                       "package": bridge.package_stats(), "check": chk}), flush=True)
 
+def work_case(name, qlen, lens, nq=1):
+    """sw_execute_work + sw_alignment_details_free for a whole package: what a Go worker calls (one C call each)."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    qs = [synth(rng, np.array([qlen]))[0].tobytes() for _ in range(nq)]
+    flat, offs = synth(rng, lens)
+    ts = [flat[int(offs[i]):int(offs[i + 1])].tobytes() for i in range(len(lens))]
+    seqs = qs + ts
+    L = bridge.lib()
+    arr = (C.c_char_p * len(seqs))(*seqs)
+    n = nq * len(ts)
+    pairs = (bridge.CWorkPair * n)(*[bridge.CWorkPair(i // len(ts), nq + i % len(ts)) for i in range(n)])
+    pkg = bridge.CWorkPackage(arr, len(seqs), pairs, n, 2, 1, 1)
+    best = bestf = 1e9
+    for _ in range(3):
+        out = (bridge.CAlignmentDetail * n)()
+        t0 = time.perf_counter(); rc = L.sw_execute_work(C.byref(pkg), out); dt = time.perf_counter() - t0
+        assert rc >= 0, bridge.last_error()
+        chk = sum(int(out[i].score) for i in range(0, n, max(1, n // 50)))
+        t1 = time.perf_counter(); L.sw_alignment_details_free(out, n); tf = time.perf_counter() - t1
+        best = min(best, dt); bestf = min(bestf, tf)
+    cells = float(qlen) * float(lens.sum()) * nq
+    print(json.dumps({"case": name, "pairs": n, "cells": cells, "call_ms": round(best * 1e3, 2), "free_ms": round(bestf * 1e3, 2),
+                      "gcups_incl_free": round(cells / (best + bestf) / 1e9, 1), "check": chk}), flush=True)
+
 which = sys.argv[1:]
 rng = np.random.default_rng(3)
 if "c1" in which: db_case("C1 1kb x 1000x[900,1100]", 1000, rng.integers(900, 1101, size=1000))
@@ -125,3 +150,5 @@ if "strips" in which:
         pair_case(f"strip timing Q={Q}", Q, 100000)
 if "b3" in which: package_case("ExecuteWork generate_synthetic_data defaults: 10 x [200,1000] vs 800 x [10k,200k]", 10, 200, 1000, 800, 10000, 200000)
 if "b3s" in which: package_case("ExecuteWork 10 x [200,1000] vs 100 x [10k,200k]", 10, 200, 1000, 100, 10000, 200000)
+if "w2" in which: work_case("sw_execute_work 8 x 1000 pairs of ~1kb", 1000, rng.integers(900, 1101, size=1000), nq=8)
+if "w5" in which: work_case("sw_execute_work 150 x 100000x150", 150, np.full(100000, 150))
