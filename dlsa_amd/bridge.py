@@ -193,6 +193,11 @@ def lib():
     # include/sw_worker.h
     L.sw_execute_work.argtypes = [C.POINTER(CWorkPackage), C.POINTER(CAlignmentDetail)]
     L.sw_execute_work.restype = C.c_int
+    L.sw_node_execute_work.argtypes = [C.c_void_p, C.POINTER(CWorkPackage), C.POINTER(CAlignmentDetail)]
+    L.sw_node_execute_work.restype = C.c_int
+    L.sw_node_align_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_size_t, CScores,
+                                      C.c_int, C.POINTER(C.POINTER(CResult))]
+    L.sw_node_align_batch.restype = C.c_int
     L.sw_alignment_details_free.argtypes = [C.POINTER(CAlignmentDetail), C.c_uint64]
     L.sw_alignment_details_free.restype = None
     L.sw_benchmark_rust.argtypes = [C.c_double, C.c_int, C.c_int]
@@ -268,8 +273,9 @@ def find_alignment_with_fallback(query, target, score):
     return None, SwHipError("All alignment functions failed to align a sequence")
 
 
-def align_batch(queries, targets, score, path=0):
-    """sw_align_batch: one GPU submission for a list of pairs; returns a list of GoResult/None."""
+def align_batch(queries, targets, score, path=0, node=None):
+    """sw_align_batch (node: sw_node_align_batch over that Node's GPUs): one submission for a list of pairs; returns
+    a list of GoResult/None."""
     L = lib()
     n = len(queries)
     # one C string per distinct Python string: a work package names the same sequence over and over
@@ -283,7 +289,10 @@ def align_batch(queries, targets, score, path=0):
     qs = (C.c_char_p * n)(*[cstr(q) for q in queries])
     ts = (C.c_char_p * n)(*[cstr(t) for t in targets])
     out = (C.POINTER(CResult) * n)()
-    rc = L.sw_align_batch(qs, ts, n, score.c(), path, out)
+    if node is not None:
+        rc = L.sw_node_align_batch(node._h, qs, ts, n, score.c(), path, out)
+    else:
+        rc = L.sw_align_batch(qs, ts, n, score.c(), path, out)
     if rc != 0:
         raise SwHipError(f"sw_align_batch failed ({rc}): {last_error()}")
     return [(_convert(L, out[i]) if out[i] else None) for i in range(n)]

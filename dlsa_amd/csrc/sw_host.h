@@ -178,13 +178,18 @@ int run_exact(Context& c, Workspace& ws, const PairSpec* specs, size_t n, Scorin
 // ---- the work-package fast path (sw_package.cpp) ------------------------------------------------------------------
 // For the pairs it is eligible for, fills po[k] (global end cell, score, ops appended to `arena`) and sets
 // handled[k]; everything else is left to the whole-matrix path.  dec: the distinct decoded sequences of the batch;
-// pair_q / pair_t: per pair, indices into dec.  Takes the default context's lock itself.
+// pair_q / pair_t: per pair, indices into dec.  Takes the lock of `device`'s context (-1: the default device) itself.
 int align_windows(const std::vector<Decoded>& dec, const std::vector<uint32_t>& pair_q, const std::vector<uint32_t>& pair_t,
-                  Scoring sc, std::vector<PairOut>& po, std::vector<uint8_t>& arena, std::vector<uint8_t>& handled);
+                  Scoring sc, std::vector<PairOut>& po, std::vector<uint8_t>& arena, std::vector<uint8_t>& handled,
+                  int device = -1);
+// A batch of pairs on one device (sw_lib.cpp): the body of sw_align_batch.  out[i] = NULL for a pair the reference
+// would have failed on; a non-zero return means nothing was handed over.
+int align_many_on(int device, const char* const* queries, const char* const* targets, size_t n, AlignmentScores as,
+                  int path, Result** out);
 struct PackageStats {
   uint64_t pairs = 0, queries = 0, windows = 0, rounds = 0, window_cells = 0, chunks = 0, chunk_escapes = 0;
 };
-extern PackageStats g_package_stats;
+extern thread_local PackageStats g_package_stats;
 
 // ---- result strings ---------------------------------------------------------------------------------------------
 char* str_alloc(size_t n);

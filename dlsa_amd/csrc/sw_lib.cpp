@@ -737,9 +737,8 @@ void swhip::parallel_ranges_impl(size_t n, unsigned nt, void (*fn)(void*, size_t
   if (failed.load()) throw std::bad_alloc();
 }
 
-namespace {
-int align_many(const char* const* queries, const char* const* targets, size_t n, AlignmentScores as, int path,
-               Result** out) {
+int swhip::align_many_on(int device, const char* const* queries, const char* const* targets, size_t n,
+                         AlignmentScores as, int path, Result** out) {
   if (n == 0) return SW_OK;
   StageTimer tm(n);
   if (!queries || !targets || !out) return fail(SW_E_ARG, "null argument");
@@ -795,7 +794,7 @@ int align_many(const char* const* queries, const char* const* targets, size_t n,
   if (path == SW_PATH_LOW_MEMORY && !specs.empty()) {
     std::vector<uint32_t> pq(specs.size()), pt(specs.size());
     for (size_t k = 0; k < specs.size(); k++) pq[k] = qi[idx[k]], pt[k] = ti[idx[k]];
-    const int rc = align_windows(dec, pq, pt, sc, po, arena, handled);
+    const int rc = align_windows(dec, pq, pt, sc, po, arena, handled, device);
     if (rc) return rc;
     tm.lap("windows");
   }
@@ -809,7 +808,7 @@ int align_many(const char* const* queries, const char* const* targets, size_t n,
       }
     if (!rest.empty()) {
       std::vector<PairOut> ro(rest.size());
-      CtxLock L(-1);
+      CtxLock L(device);
       if (L.rc) return L.rc;
       const int rc = run_exact(*L.c, L.c->ws, rest.data(), rest.size(), sc, true, ro.data(), &arena);
       if (rc) return rc;
@@ -884,6 +883,7 @@ int align_many(const char* const* queries, const char* const* targets, size_t n,
   return SW_OK;
 }
 
+namespace {
 // ---- one pair per call, many callers: combining ---------------------------------------------------------------
 // The Go worker enters the drop-in ABI from NumCPU-1 goroutines, one pair per call (worker_impl.go:204-238).  A GPU
 // round trip costs a few hundred microseconds whatever the batch size, so concurrent callers are COMBINED: a caller
@@ -926,7 +926,7 @@ void combine_run_batch(std::vector<OneReq*>& batch) {
     }
     g_err.clear();
     const int rc = swhip::guarded<int>(SW_E_NOMEM, [&] {
-      return align_many(qs.data(), ts.data(), grp.size(), batch[i]->as, batch[i]->path, out.data());
+      return align_many_on(-1, qs.data(), ts.data(), grp.size(), batch[i]->as, batch[i]->path, out.data());
     });
     for (size_t k = 0; k < grp.size(); k++) {
       OneReq* r = batch[grp[k]];
@@ -1089,7 +1089,7 @@ int sw_align_batch(const char* const* queries, const char* const* targets, size_
                    int path, Result** out) {
   if (out)
     for (size_t i = 0; i < n_pairs; i++) out[i] = nullptr;
-  const int rc = swhip::guarded<int>(SW_E_NOMEM, [&] { return align_many(queries, targets, n_pairs, scores, path, out); });
+  const int rc = swhip::guarded<int>(SW_E_NOMEM, [&] { return align_many_on(-1, queries, targets, n_pairs, scores, path, out); });
   if (rc != SW_OK && out)  // nothing is handed over on failure
     for (size_t i = 0; i < n_pairs; i++) {
       free_alignment_result(out[i]);

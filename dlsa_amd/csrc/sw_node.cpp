@@ -17,6 +17,7 @@
 #include <memory>
 #include <numeric>
 #include <thread>
+#include <unordered_map>
 
 #include "sw_host.h"
 
@@ -100,6 +101,111 @@ void node_db_release(sw_node_db* ndb) {
   if (!ndb) return;
   for (sw_db* d : ndb->shards) sw_db_free(d);
   delete ndb;
+}
+
+// ---- a batch of pairs over the GPUs of the node -------------------------------------------------------------------
+// The reference's unit of distribution is the (query, target) pair (proportional_work_scheduler.py:30-55); inside a
+// node the same holds: pairs are independent, so the batch is cut into one part per shard and every part is an
+// ordinary single-GPU batch (align_many_on) on its own host thread.  Pairs of one query stay together where the
+// balance allows it -- the work-package fast path (sw_package.cpp) works per query -- and parts are balanced by
+// cells: a query's group heavier than half a shard's share is cut into pieces of consecutive pairs, and pieces are
+// dealt heaviest-first to the lightest shard (LPT; ties go to the lowest shard, so the split is deterministic).
+void split_pairs(const char* const* queries, const char* const* targets, size_t n, size_t S,
+                 std::vector<std::vector<size_t>>& part) {
+  std::unordered_map<const char*, uint64_t> len;
+  auto length_of = [&](const char* s) -> uint64_t {
+    if (!s) return 0;
+    auto it = len.find(s);
+    if (it != len.end()) return it->second;
+    const uint64_t l = strlen(s);
+    len.emplace(s, l);
+    return l;
+  };
+  std::unordered_map<const char*, uint32_t> gid;
+  std::vector<std::vector<size_t>> groups;
+  std::vector<uint64_t> w(n);
+  uint64_t total = 0;
+  for (size_t i = 0; i < n; i++) {
+    // cells, plus a per-pair term for the host work around short pairs (decode, strings)
+    w[i] = (length_of(queries[i]) + 1) * (length_of(targets[i]) + 1) + 4096;
+    total += w[i];
+    auto it = gid.find(queries[i]);
+    if (it == gid.end()) {
+      it = gid.emplace(queries[i], (uint32_t)groups.size()).first;
+      groups.emplace_back();
+    }
+    groups[it->second].push_back(i);
+  }
+  struct Piece {
+    uint64_t w;
+    uint32_t group;
+    size_t lo, hi;
+  };
+  std::vector<Piece> pieces;
+  const uint64_t cap = std::max<uint64_t>(1, total / (2 * S));
+  for (uint32_t g = 0; g < groups.size(); g++) {
+    size_t lo = 0;
+    uint64_t acc = 0;
+    for (size_t k = 0; k < groups[g].size(); k++) {
+      acc += w[groups[g][k]];
+      if (acc >= cap || k + 1 == groups[g].size()) {
+        pieces.push_back(Piece{acc, g, lo, k + 1});
+        lo = k + 1;
+        acc = 0;
+      }
+    }
+  }
+  std::stable_sort(pieces.begin(), pieces.end(), [](const Piece& a, const Piece& b) { return a.w > b.w; });
+  std::vector<uint64_t> load(S, 0);
+  part.assign(S, {});
+  for (const Piece& pc : pieces) {
+    size_t best = 0;
+    for (size_t s = 1; s < S; s++)
+      if (load[s] < load[best]) best = s;
+    load[best] += pc.w;
+    for (size_t k = pc.lo; k < pc.hi; k++) part[best].push_back(groups[pc.group][k]);
+  }
+  for (auto& v : part) std::sort(v.begin(), v.end());  // the caller's order inside a part
+}
+
+int node_align_batch(const sw_node* node, const char* const* queries, const char* const* targets, size_t n,
+                     AlignmentScores as, int path, Result** out) {
+  if (!node || node->devices.empty() || (n && (!queries || !targets || !out))) return fail(SW_E_ARG, "bad argument");
+  if (path < 0 || path > 2) return fail(SW_E_ARG, "bad path");
+  for (size_t i = 0; i < n; i++) out[i] = nullptr;
+  const size_t S = node->devices.size();
+  if (S == 1 || n < 2) return align_many_on(node->devices[0], queries, targets, n, as, path, out);
+  std::vector<std::vector<size_t>> part;
+  split_pairs(queries, targets, n, S, part);
+  std::vector<PackageStats> st(S);
+  const int rc = on_every_shard(S, [&](size_t s) -> int {
+    const std::vector<size_t>& mine = part[s];
+    if (mine.empty()) return SW_OK;
+    std::vector<const char*> qs(mine.size()), ts(mine.size());
+    for (size_t k = 0; k < mine.size(); k++) qs[k] = queries[mine[k]], ts[k] = targets[mine[k]];
+    std::vector<Result*> res(mine.size(), nullptr);
+    g_package_stats = PackageStats{};
+    const int r = align_many_on(node->devices[s], qs.data(), ts.data(), mine.size(), as, path, res.data());
+    st[s] = g_package_stats;
+    if (r) return r;
+    for (size_t k = 0; k < mine.size(); k++) out[mine[k]] = res[k];
+    return SW_OK;
+  });
+  if (rc) {  // nothing is handed over
+    const std::string msg = last_error_string();
+    for (size_t i = 0; i < n; i++) {
+      if (out[i]) free_alignment_result(out[i]);
+      out[i] = nullptr;
+    }
+    return fail(rc, msg);
+  }
+  PackageStats sum;
+  for (const PackageStats& p : st) {
+    sum.pairs += p.pairs, sum.queries += p.queries, sum.windows += p.windows, sum.rounds += p.rounds;
+    sum.window_cells += p.window_cells, sum.chunks += p.chunks, sum.chunk_escapes += p.chunk_escapes;
+  }
+  g_package_stats = sum;
+  return SW_OK;
 }
 
 int node_search(sw_node_db* ndb, const char* const* queries, size_t n_queries, AlignmentScores as, int k, sw_hit* hits,
@@ -359,6 +465,11 @@ int sw_node_last_stats(const sw_node_db* ndb, int shard, sw_kernel_stats* out) {
   if (L.rc) return L.rc;
   *out = L.c->stats;
   return SW_OK;
+}
+
+int sw_node_align_batch(const sw_node* node, const char* const* queries, const char* const* targets, size_t n_pairs,
+                        AlignmentScores scores, int path, Result** out) {
+  return guarded<int>(SW_E_NOMEM, [&] { return node_align_batch(node, queries, targets, n_pairs, scores, path, out); });
 }
 
 float sw_node_benchmark_cups(sw_node* node) {

@@ -49,12 +49,12 @@ struct DbHolder {
 
 namespace swhip {
 // counters of the last package through the fast path (test hook / profiling)
-PackageStats g_package_stats;
+thread_local PackageStats g_package_stats;  // of the calling thread's last batch (sw_node_align_batch sums its threads')
 }
 
 int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint32_t>& pair_q,
                          const std::vector<uint32_t>& pair_t, Scoring sc, std::vector<PairOut>& po,
-                         std::vector<uint8_t>& arena, std::vector<uint8_t>& handled) {
+                         std::vector<uint8_t>& arena, std::vector<uint8_t>& handled, int device) {
   const size_t n = pair_q.size();
   handled.assign(n, 0);
   g_package_stats = PackageStats{};
@@ -78,7 +78,7 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
   }
   if (cells < 1e7) return SW_OK;  // a handful of small matrices: the whole-matrix path is just as fast
   Context* ctx = nullptr;
-  int rc = ctx_get(-1, &ctx);
+  int rc = ctx_get(device, &ctx);
   if (rc) return rc;
   PackageStats st{};
   // ---- one temporary database per distinct target set (a package is normally a few queries x one target set)

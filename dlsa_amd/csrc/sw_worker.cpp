@@ -52,7 +52,8 @@ bool fill_detail(sw_alignment_detail& d, Result* r, int entry) {
 
 extern "C" {
 
-static int execute_work(const sw_work_package* work, sw_alignment_detail* out, bool& out_initialised) {
+static int execute_work(const sw_node* node, const sw_work_package* work, sw_alignment_detail* out,
+                        bool& out_initialised) {
   if (!work || (work->n_pairs && (!work->pairs || !out)) || (work->n_sequences && !work->sequences)) {
     set_last_error("sw_execute_work: null argument");
     return SW_E_ARG;
@@ -87,7 +88,8 @@ static int execute_work(const sw_work_package* work, sw_alignment_detail* out, b
       ts[k] = work->sequences[work->pairs[todo[k]].target];
     }
     std::vector<Result*> res(todo.size(), nullptr);
-    const int rc = sw_align_batch(qs.data(), ts.data(), todo.size(), sc, chain[level], res.data());
+    const int rc = node ? sw_node_align_batch(node, qs.data(), ts.data(), todo.size(), sc, chain[level], res.data())
+                        : sw_align_batch(qs.data(), ts.data(), todo.size(), sc, chain[level], res.data());
     if (rc != SW_OK) {
       sw_alignment_details_free(out, n);
       return rc;  // no GPU / HIP failure: nothing can be computed (message already recorded)
@@ -119,15 +121,27 @@ static int execute_work(const sw_work_package* work, sw_alignment_detail* out, b
   return SW_W_FAILED_PAIRS + (int)std::min<size_t>(todo.size(), 0x7fffffff);
 }
 
-int sw_execute_work(const sw_work_package* work, sw_alignment_detail* out) {
+static int execute_work_guarded(const sw_node* node, const sw_work_package* work, sw_alignment_detail* out) {
   bool out_initialised = false, returned = false;
   const int rc = swhip::guarded<int>(SW_E_NOMEM, [&] {
-    const int r = execute_work(work, out, out_initialised);
+    const int r = execute_work(node, work, out, out_initialised);
     returned = true;
     return r;
   });
   if (!returned && out_initialised) sw_alignment_details_free(out, work->n_pairs);  // left by an exception
   return rc;
+}
+
+int sw_execute_work(const sw_work_package* work, sw_alignment_detail* out) {
+  return execute_work_guarded(nullptr, work, out);
+}
+
+int sw_node_execute_work(const sw_node* node, const sw_work_package* work, sw_alignment_detail* out) {
+  if (!node) {
+    set_last_error("sw_node_execute_work: null node");
+    return SW_E_ARG;
+  }
+  return execute_work_guarded(node, work, out);
 }
 
 void sw_alignment_details_free(sw_alignment_detail* d, uint64_t n) {

@@ -87,9 +87,11 @@ class Worker:
     """Worker of internal/worker/worker_impl.go:18-23 without the REST client: results are handed to `send_result`
     (RestClient.SendResult, :161,166) -- by default collected in self.sent."""
 
-    def __init__(self, send_result=None):
+    def __init__(self, send_result=None, node=None):
+        """node: a bridge.Node -- every work package is then spread over that node's GPUs (sw_node_execute_work)."""
         self.sent: List[WorkResult] = []
         self._send = send_result or self.sent.append
+        self.node = node
 
     def align(self, work: CompleteWorkPackage, queries: List[QueryTargetType]) -> List[AlignmentDetail]:
         """All AlignmentDetails of `queries`, in order: one sw_execute_work call."""
@@ -106,7 +108,10 @@ class Worker:
         pairs = (bridge.CWorkPair * n)(*[bridge.CWorkPair(index[c.query], index[c.target]) for c in queries])
         pkg = bridge.CWorkPackage(seqs, len(ids), pairs, n, work.match_score, work.mismatch_penalty, work.gap_penalty)
         out = (bridge.CAlignmentDetail * n)()
-        rc = L.sw_execute_work(C.byref(pkg), out)
+        if self.node is not None:
+            rc = L.sw_node_execute_work(self.node._h, C.byref(pkg), out)
+        else:
+            rc = L.sw_execute_work(C.byref(pkg), out)
         if rc < 0:  # (rc > 0: that many pairs failed on every entry point -- entry == -1 below)
             raise SwHipError(f"sw_execute_work failed ({rc}): {bridge.last_error()}")
         self.failed_pairs = rc

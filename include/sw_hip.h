@@ -188,6 +188,14 @@ int sw_hip_last_stats(struct sw_kernel_stats *out);
  * master/api_models/worker.py:7-16): cells per second of the batch path on synthetic DNA, as a
  * float32-representable INTEGER-valued number (the master's field is a pydantic int). */
 float sw_hip_benchmark_cups(void);
+/* sw_align_batch over the GPUs of a node: the pairs are cut into one part per shard of the handle (pairs of one
+ * query kept together where the balance allows, parts balanced by cells, deterministic), every part runs as an
+ * ordinary batch on its device at the same time, and out[i] is what sw_align_batch would have written -- pairs are
+ * independent, so the split cannot change a result.  The reference distributes by pair over worker processes
+ * (master/work_package/_scheduler/proportional_work_scheduler.py:30-55); this is the same split inside one
+ * process.  On failure nothing is handed over. */
+int sw_node_align_batch(const sw_node *node, const char *const *queries, const char *const *targets, size_t n_pairs,
+                        struct AlignmentScores scores, int path, struct Result **out);
 /* The same for a whole node: every distinct device of the handle runs the benchmark at the same time and the
  * figures are added -- the number a one-process-per-node GPU worker registers with the master. */
 float sw_node_benchmark_cups(sw_node *node);

@@ -64,6 +64,9 @@ struct sw_alignment_detail {
  * failed on all three entries: out[i].entry == -1, empty strings -- the reference dereferences nil there,
  * worker_impl.go:136) or a negative SW_E_* code when nothing could be computed (no GPU, bad index). */
 int sw_execute_work(const struct sw_work_package *work, struct sw_alignment_detail *out);
+/* The same over the GPUs of a node handle (sw_node_align_batch per fallback level): what a one-process-per-node
+ * GPU worker, registered with sw_node_benchmark_cups(), calls per work package.  Same results, same return codes. */
+int sw_node_execute_work(const sw_node *node, const struct sw_work_package *work, struct sw_alignment_detail *out);
 void sw_alignment_details_free(struct sw_alignment_detail *details, uint64_t n);
 
 /* ---- capacity benchmark -------------------------------------------------------------------------------------

@@ -119,3 +119,48 @@ def test_node_capacity_benchmark_is_integer_valued():
         assert cups > 1e11 and cups == float(int(cups))
     finally:
         node.close()
+
+
+@pytest.mark.parametrize("n_shards", [2, 3])
+def test_node_batch_and_execute_work_equal_the_single_gpu_calls(oracle, n_shards):
+    """sw_node_align_batch / sw_node_execute_work: the pairs of one package are cut over the node's shards (by query,
+    balanced by cells), every part is an ordinary batch, and each pair's result is the one the single-GPU call gives
+    -- and the oracle's.  Mixed package: fast-path pairs (long targets), short pairs, failures, a non-ASCII pair."""
+    import dlsa_amd
+    from dlsa_amd import bridge, worker
+    rng = random.Random(77)
+    sc = (-1, 2, -1)
+    s = dlsa_amd.AlignmentScore(sc[1], sc[2], sc[0])
+    queries = [_rnd(rng, n) for n in (120, 300, 64, 900)]
+    long_t = [_rnd(rng, rng.randint(9000, 22000)) for _ in range(6)]
+    long_t[2] = long_t[2][:5000] + queries[3][100:800] + long_t[2][5000:]
+    short_t = [_rnd(rng, rng.randint(1, 700)) for _ in range(40)] + ["", "N" * 12, "ACGTÄCGT" * 5]
+    targets = long_t + short_t
+    qs = [q for q in queries for _ in targets]
+    ts = targets * len(queries)
+    node = bridge.Node(devices=[0] * n_shards)
+    try:
+        got = bridge.align_batch(qs, ts, s, 0, node=node)
+        st = bridge.package_stats()
+        assert st["pairs"] == len(queries) * len(long_t)          # summed over the shards' threads
+        ref = bridge.align_batch(qs, ts, s, 0)
+        for g, r, q, t in zip(got, ref, qs, ts):
+            assert (g is None) == (r is None)
+            if g is None:
+                continue
+            assert (g.score, g.max_x, g.max_y, g.query, g.target) == (r.score, r.max_x, r.max_y, r.query, r.target)
+            e = oracle.align("lowmem", q, t, *sc)
+            assert (g.score, g.max_x, g.max_y, g.query, g.target) == (e["score"], e["max_x"], e["max_y"], e["q"], e["t"])
+        # the worker's entry: one package, every pair
+        seqs = {f"s{i}": v for i, v in enumerate(queries + targets)}
+        pairs = [worker.QueryTargetType(f"s{qi}", f"s{len(queries) + ti}")
+                 for qi in range(len(queries)) for ti in range(len(targets))]
+        work = worker.CompleteWorkPackage("wp", "job", pairs, 2, 1, 1, seqs)
+        a = worker.Worker(node=node).align(work, pairs)
+        b = worker.Worker().align(work, pairs)
+        assert len(a) == len(pairs)
+        for x, y in zip(a, b):
+            assert x.combination == y.combination and x.entry == y.entry and x.score32 == y.score32
+            assert vars(x.alignment) == vars(y.alignment)
+    finally:
+        node.close()
