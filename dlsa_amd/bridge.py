@@ -193,6 +193,8 @@ def lib():
     # include/sw_worker.h
     L.sw_execute_work.argtypes = [C.POINTER(CWorkPackage), C.POINTER(CAlignmentDetail)]
     L.sw_execute_work.restype = C.c_int
+    L.sw_free_alignment_results.argtypes = [C.POINTER(C.POINTER(CResult)), C.c_size_t]
+    L.sw_free_alignment_results.restype = None
     L.sw_node_execute_work.argtypes = [C.c_void_p, C.POINTER(CWorkPackage), C.POINTER(CAlignmentDetail)]
     L.sw_node_execute_work.restype = C.c_int
     L.sw_node_align_batch.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_size_t, CScores,

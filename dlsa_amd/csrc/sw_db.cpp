@@ -963,7 +963,8 @@ int swhip::db_align_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring 
   std::vector<PairSpec> specs;
   std::vector<Decoded> tdec(total);
   std::vector<PairOut> po(total);
-  std::vector<uint8_t> arena;
+  ArenaLease lease;
+  OpsArena& arena = lease.a;
   specs.reserve(total);
   for (size_t i = 0; i < total; i++) {
     const HitRef& r = refs[i];

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
+#include <new>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -55,11 +56,33 @@ struct HostBuf {
   void release();
 };
 
+// std::allocator without value-initialisation: resize() of a big host table does not write it first
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInitAlloc<U>; };
+  NoInitAlloc() = default;
+  template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+  template <class U, class... A> void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+    else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+};
+// Host tables of one exact-path submission (run_exact_chunk), kept between calls: a work package of 10^5 pairs needs
+// ~12 MB of them, and fresh vectors cost more in page faults than filling them does.
+struct ExactHost {
+  std::vector<ExactPair, NoInitAlloc<ExactPair>> hp;
+  std::vector<size_t, NoInitAlloc<size_t>> qoff, toff, dirw;
+  std::vector<uint32_t> unit_pair, unit_order;
+  void trim();  // gives the memory back when a submission was unusually large
+};
+
 // Everything a submission needs beyond its inputs and outputs.  A context owns two: `ws` grows on demand
 // (hipMalloc), `na` is carved out of the per-device static scratch array once, at set-up.
 struct Workspace {
   DevBuf xin, xzero, xout, dirs, xrecs;                    // exact path (run_exact_chunk)
   HostBuf h_in, h_out;                                     // ... its host staging buffers
+  ExactHost xh;                                            // ... and host tables
+  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr;  // ... kernel bracket and completion (made on first use)
   DevBuf sel_hist, sel_ctr, sel_rerun, sel_cand, sel_tie;  // device-side top-k selection
   DevBuf qwords, slot_scores, gbound, ticket, prog, units; // score path
   DevBuf strip_best;                                       // ... per-strip maxima (work-package fast path)
@@ -89,6 +112,7 @@ struct Context {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   Workspace ws;
+  Workspace ws2;  // second set for submissions in flight while the first is being read back (work packages)
   // the allocation-free entry point (sw_db_scores_noalloc): windows of this device's copy of the static scratch
   // array (sw_lib.cpp) and a host arena, both bound once when the context is created
   Workspace na;
@@ -118,8 +142,12 @@ struct CtxLock {
 // submission): every function that queues work holds one of these; on the success path the stream is idle already.
 struct StreamDrain {
   hipStream_t s;
+  bool armed = true;
   explicit StreamDrain(hipStream_t st) : s(st) {}
-  ~StreamDrain() { (void)hipStreamSynchronize(s); }
+  void dismiss() { armed = false; }  // the work stays queued on purpose: the caller holds another drain further out
+  ~StreamDrain() {
+    if (armed) (void)hipStreamSynchronize(s);
+  }
   StreamDrain(const StreamDrain&) = delete;
   StreamDrain& operator=(const StreamDrain&) = delete;
 };
@@ -127,11 +155,54 @@ struct StreamDrain {
 // ---- text -> symbols ----------------------------------------------------------------------------------------
 // A sequence as the algorithm sees it: Unicode scalars truncated to u16 (`*x as u16`,
 // rust/src/algorithm/mod.rs:78,224).  Pure-ASCII input (the normal case: DNA) never materialises code points.
+// The symbols of one sequence: a vector of its own, or -- bind() -- a stretch of a pool that the caller owns and that
+// has room for every later resize() (a work package decodes 10^5 sequences: one pool instead of 10^5 heap blocks).
+class SymBuf {
+  std::vector<uint16_t, NoInitAlloc<uint16_t>> own_;
+  uint16_t* p_ = nullptr;
+  size_t n_ = 0;
+  bool ext_ = false;
+
+ public:
+  SymBuf() = default;
+  SymBuf(const SymBuf& o) { *this = o; }
+  SymBuf& operator=(const SymBuf& o) {
+    if (this != &o) {
+      own_.assign(o.data(), o.data() + o.size());
+      p_ = own_.data();
+      n_ = own_.size();
+      ext_ = false;
+    }
+    return *this;
+  }
+  SymBuf(SymBuf&&) = default;  // (a moved vector keeps its block, so p_ stays right)
+  SymBuf& operator=(SymBuf&&) = default;
+  void bind(uint16_t* pool) {
+    p_ = pool;
+    n_ = 0;
+    ext_ = true;
+  }
+  void resize(size_t n) {
+    if (!ext_) {
+      own_.resize(n);
+      p_ = own_.data();
+    }
+    n_ = n;
+  }
+  uint16_t* data() { return p_; }
+  const uint16_t* data() const { return p_; }
+  size_t size() const { return n_; }
+  bool empty() const { return n_ == 0; }
+  uint16_t& operator[](size_t i) { return p_[i]; }
+  const uint16_t& operator[](size_t i) const { return p_[i]; }
+  const uint16_t* begin() const { return p_; }
+  const uint16_t* end() const { return p_ + n_; }
+};
 struct Decoded {
   const char* src = nullptr;  // borrowed
   bool ascii = true;
   std::vector<uint32_t> cps;  // only when !ascii: for re-encoding the alignment
-  std::vector<uint16_t> sym;
+  SymBuf sym;
   uint32_t cp(size_t i) const { return ascii ? (uint32_t)(unsigned char)src[i] : cps[i]; }
 };
 bool decode(const char* s, size_t n, Decoded& d);
@@ -169,23 +240,60 @@ struct PairOut {
 struct PathParams {
   uint32_t Tlim, T0, phaseQp, straight;
 };
+// Traceback ops of a submission (one byte per alignment column, PairOut::ops_off / nops index it).  Tens of
+// megabytes for a work package of 10^5 pairs, so: no value-initialisation on resize (the bytes are overwritten by a
+// device-to-host copy), and the storage is leased from a small pool and given back with its pages already mapped
+// and pinned (ArenaLease) instead of being allocated afresh on every call.  Always use it through a lease: a
+// stand-alone OpsArena pays a hipHostMalloc per growth step.
+// ... in page-locked host memory, so that the device-to-host copy of the ops lands in it directly at link speed
+template <class T>
+struct PinnedNoInitAlloc {
+  using value_type = T;
+  template <class U> struct rebind { using other = PinnedNoInitAlloc<U>; };
+  PinnedNoInitAlloc() = default;
+  template <class U> PinnedNoInitAlloc(const PinnedNoInitAlloc<U>&) {}
+  T* allocate(size_t n) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, n * sizeof(T), hipHostMallocPortable) != hipSuccess || !p) throw std::bad_alloc();
+    return (T*)p;
+  }
+  void deallocate(T* p, size_t) { (void)hipHostFree(p); }
+  template <class U, class... A> void construct(U* p, A&&... a) {
+    if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+    else ::new ((void*)p) U(std::forward<A>(a)...);
+  }
+  template <class U> bool operator==(const PinnedNoInitAlloc<U>&) const { return true; }
+  template <class U> bool operator!=(const PinnedNoInitAlloc<U>&) const { return false; }
+};
+using OpsArena = std::vector<uint8_t, PinnedNoInitAlloc<uint8_t>>;
+struct ArenaLease {
+  OpsArena a;
+  ArenaLease();
+  ~ArenaLease();
+  ArenaLease(const ArenaLease&) = delete;
+  ArenaLease& operator=(const ArenaLease&) = delete;
+};
 PathParams resolve_path(int path, uint32_t Q, uint32_t T);
 bool ring_div_by_zero(int path, uint32_t Q, uint32_t T, Scoring sc);
 // Caller holds the context's lock.
 int run_exact(Context& c, Workspace& ws, const PairSpec* specs, size_t n, Scoring sc, bool want_trace, PairOut* outs,
-              std::vector<uint8_t>* arena = nullptr);
+              OpsArena* arena = nullptr);
 
 // ---- the work-package fast path (sw_package.cpp) ------------------------------------------------------------------
 // For the pairs it is eligible for, fills po[k] (global end cell, score, ops appended to `arena`) and sets
 // handled[k]; everything else is left to the whole-matrix path.  dec: the distinct decoded sequences of the batch;
 // pair_q / pair_t: per pair, indices into dec.  Takes the lock of `device`'s context (-1: the default device) itself.
 int align_windows(const std::vector<Decoded>& dec, const std::vector<uint32_t>& pair_q, const std::vector<uint32_t>& pair_t,
-                  Scoring sc, std::vector<PairOut>& po, std::vector<uint8_t>& arena, std::vector<uint8_t>& handled,
+                  Scoring sc, std::vector<PairOut>& po, OpsArena& arena, std::vector<uint8_t>& handled,
                   int device = -1);
 // A batch of pairs on one device (sw_lib.cpp): the body of sw_align_batch.  out[i] = NULL for a pair the reference
 // would have failed on; a non-zero return means nothing was handed over.
 int align_many_on(int device, const char* const* queries, const char* const* targets, size_t n, AlignmentScores as,
                   int path, Result** out);
+// The same for pairs given as indices into a table of distinct sequences (UINT32_MAX or a NULL entry: the pair
+// fails) -- what a work package holds (sw_worker.cpp), so that nothing has to be re-discovered from pointers.
+int align_interned(int device, const char* const* distinct, size_t n_distinct, const uint32_t* qi, const uint32_t* ti,
+                   size_t n, AlignmentScores as, int path, Result** out);
 struct PackageStats {
   uint64_t pairs = 0, queries = 0, windows = 0, rounds = 0, window_cells = 0, chunks = 0, chunk_escapes = 0;
 };

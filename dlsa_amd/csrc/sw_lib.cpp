@@ -264,12 +264,34 @@ PathParams swhip::resolve_path(int path, uint32_t Q, uint32_t T) {
 
 
 namespace {
-// Runs pairs [begin, end) in one submission.  Caller holds the context mutex.
-int run_exact_chunk(Context& c, Workspace& ws, const PairSpec* specs, size_t begin, size_t end, Scoring sc,
-                    bool want_trace, PairOut* outs, std::vector<uint8_t>* arena, int rpl) {
+// One submission of pairs [begin, end), in two halves so that a driver can keep two in flight (a work package:
+// the next sub-batch is staged and queued while this one is on the GPU).  Caller holds the context mutex.
+struct ChunkJob {
+  size_t begin = 0, n = 0, out_ops = 0, ops_bytes = 0, arena_base = 0;
+  bool want_trace = false, one_copy = false, full_copy = false;
+  uint8_t* d_out = nullptr;
+  const PairSpec* specs = nullptr;
+  OpsArena* arena = nullptr;
+};
+int ws_events(Workspace& ws) {
+  for (hipEvent_t* e : {&ws.ev_k0, &ws.ev_k1, &ws.ev_done})
+    if (!*e) HIPCK(hipEventCreate(e));
+  return SW_OK;
+}
+// Stages and queues everything, including the copies back; returns without waiting.  full_copy: the whole ops
+// region (capacity Q + T per pair) is copied straight into the arena instead of only the bytes the walkers wrote,
+// which needs no second round trip -- right for many short pairs.  On success the work is in flight and the caller
+// must call exact_chunk_end (or drain the stream) before touching ws or the arena again.
+int exact_chunk_begin(Context& c, Workspace& ws, const PairSpec* specs, size_t begin, size_t end, Scoring sc,
+                      bool want_trace, OpsArena* arena, int rpl, bool full_copy, ChunkJob& job) {
   const size_t n = end - begin;
+  job = ChunkJob{};
+  job.begin = begin;
+  job.n = n;
   if (n == 0) return SW_OK;
   StageTimer tm(n);
+  int erc = ws_events(ws);
+  if (erc) return erc;
   // symbol pool: every distinct sequence once (a database search shares one query)
   std::unordered_map<const uint16_t*, size_t> seen;  // pointer -> index into copies
   std::vector<size_t> copy_by_id;                    // id -> index into copies
@@ -298,39 +320,63 @@ int run_exact_chunk(Context& c, Workspace& ws, const PairSpec* specs, size_t beg
     else seen[p] = copies.size() - 1;
     return off;
   };
-  std::vector<ExactPair> hp(n);
-  std::vector<size_t> qoff(n), toff(n);
+  struct Trim {
+    ExactHost& h;
+    ~Trim() { h.trim(); }
+  } trim{ws.xh};
+  auto& hp = ws.xh.hp;
+  auto& qoff = ws.xh.qoff;
+  auto& toff = ws.xh.toff;
+  auto& dirw = ws.xh.dirw;
+  auto& unit_pair = ws.xh.unit_pair;
+  auto& unit_order = ws.xh.unit_order;
+  hp.resize(n);
+  qoff.resize(n);
+  toff.resize(n);
+  dirw.resize(want_trace ? n : 0);
+  unit_pair.clear();
+  unit_order.clear();
   size_t dir_words = 0, bnd_ints = 0, ops_bytes = 0;
-  std::vector<uint32_t> unit_pair;
   unit_pair.reserve(n);
   copies.reserve(n + 1);
+  tm.lap("  chunk: alloc");
+  // per pair, independent of every other pair: on the host threads when the submission is a whole work package
+  parallel_ranges(n, n * 256, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      const PairSpec& s = specs[begin + i];
+      PathParams pp = resolve_path(s.path, s.Qfull ? s.Qfull : s.Q, s.Tfull ? s.Tfull : s.T);
+      if (s.Tfull) {  // a window: the column limits are global, the kernel counts columns from col0
+        pp.Tlim = pp.Tlim > s.col0 ? std::min(pp.Tlim - s.col0, s.T) : 0;
+        pp.T0 = pp.T0 > s.col0 ? std::min(pp.T0 - s.col0, s.T) : 0;
+      }
+      ExactPair& e = hp[i];
+      e.Q = s.Q;
+      e.T = s.T;
+      e.left = s.left;
+      e.left_shift = s.left_shift;
+      e.col0 = s.col0;
+      e.Tfull = s.Tfull;
+      e.walk_x = s.walk_x;
+      e.walk_j = s.walk_j;
+      e.walk_H = s.walk_H;
+      e.Tlim = pp.Tlim;
+      e.T0 = pp.T0;
+      e.phaseQp = pp.phaseQp;
+      e.straight = pp.straight;
+      const uint32_t maxcol = std::max(pp.Tlim, pp.T0);
+      e.bnd_pitch = maxcol + 2;
+      e.nkb = exact_nsteps(maxcol) / 16;
+      e.n_units = std::max<uint32_t>(exact_nstrips(s.Q, rpl), 1);
+      if (want_trace) dirw[i] = exact_dir_words(s.Q, maxcol, rpl);
+    }
+  });
+  tm.lap("  chunk: per pair");
+  // what depends on the pairs before: the symbol pool, the unit numbering and the offsets into the shared buffers
   for (size_t i = 0; i < n; i++) {
     const PairSpec& s = specs[begin + i];
     qoff[i] = add_seq(s.q, s.Q, s.qid);
     toff[i] = add_seq(s.t, s.T, s.tid);
-    PathParams pp = resolve_path(s.path, s.Qfull ? s.Qfull : s.Q, s.Tfull ? s.Tfull : s.T);
-    if (s.Tfull) {  // a window: the column limits are global, the kernel counts columns from col0
-      pp.Tlim = pp.Tlim > s.col0 ? std::min(pp.Tlim - s.col0, s.T) : 0;
-      pp.T0 = pp.T0 > s.col0 ? std::min(pp.T0 - s.col0, s.T) : 0;
-    }
     ExactPair& e = hp[i];
-    e.Q = s.Q;
-    e.T = s.T;
-    e.left = s.left;
-    e.left_shift = s.left_shift;
-    e.col0 = s.col0;
-    e.Tfull = s.Tfull;
-    e.walk_x = s.walk_x;
-    e.walk_j = s.walk_j;
-    e.walk_H = s.walk_H;
-    e.Tlim = pp.Tlim;
-    e.T0 = pp.T0;
-    e.phaseQp = pp.phaseQp;
-    e.straight = pp.straight;
-    const uint32_t maxcol = std::max(pp.Tlim, pp.T0);
-    e.bnd_pitch = maxcol + 2;
-    e.nkb = exact_nsteps(maxcol) / 16;
-    e.n_units = std::max<uint32_t>(exact_nstrips(s.Q, rpl), 1);
     if (unit_pair.size() + e.n_units > 0x7fffff00ull) return fail(SW_E_ARG, "too many strips in one submission");
     e.first_unit = (uint32_t)unit_pair.size();
     unit_pair.insert(unit_pair.end(), e.n_units, (uint32_t)i);
@@ -339,7 +385,7 @@ int run_exact_chunk(Context& c, Workspace& ws, const PairSpec* specs, size_t beg
     bnd_ints += (size_t)e.n_units * e.bnd_pitch;
     if (want_trace) {
       e.dirs = (uint32_t*)(uintptr_t)(dir_words + 1);  // +1 so that offset 0 is not nullptr
-      dir_words += exact_dir_words(s.Q, maxcol, rpl);
+      dir_words += dirw[i];
       e.ops = (uint8_t*)(uintptr_t)ops_bytes;
       ops_bytes += ((size_t)s.Q + s.T + 15) / 16 * 16;
     } else {
@@ -348,11 +394,11 @@ int run_exact_chunk(Context& c, Workspace& ws, const PairSpec* specs, size_t beg
     }
   }
   const size_t n_units = unit_pair.size();
+  tm.lap("  chunk: offsets");
   // Ticket order: strip level by level (all pairs' strip 0, then every strip 1, ...; longest pairs first within a
   // level), so that in a big submission the strip above has long finished when a strip starts, instead of the
   // strips of one pair trailing each other through HBM with adjacent tickets.  The strip above always has an
   // EARLIER ticket, which is all the kernel needs.  unit_order[ticket] = record index (first_unit + strip).
-  std::vector<uint32_t> unit_order;
   unit_order.reserve(n_units);
   {
     uint32_t max_units = 0;
@@ -403,14 +449,17 @@ int run_exact_chunk(Context& c, Workspace& ws, const PairSpec* specs, size_t beg
   memcpy(h_in + in_pairs, hp.data(), n * sizeof(ExactPair));
   memcpy(h_in + in_units, unit_pair.data(), n_units * 4);
   memcpy(h_in + in_order, unit_order.data(), n_units * 4);
-  for (const SeqCopy& sc_ : copies) memcpy(h_in + in_sym + sc_.off * 2, sc_.p, (size_t)sc_.len * 2);
+  parallel_ranges(copies.size(), pool_syms * 2, [&](size_t lo, size_t hi) {
+    for (size_t k = lo; k < hi; k++)
+      memcpy(h_in + in_sym + copies[k].off * 2, copies[k].p, (size_t)copies[k].len * 2);
+  });
   tm.lap("  chunk: stage");
   // any error return from here on leaves work queued that reads / writes the staging buffers: drain it first
   StreamDrain drain(c.stream);
   HIPCK(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, c.stream));
   // (strip boundary rows: a word is "published" when its bit 31 is set (sw_exact.hip), so they start at zero)
   HIPCK(hipMemsetAsync(d_zero, 0, z_bytes, c.stream));
-  HIPCK(hipEventRecord(c.ev2, c.stream));
+  HIPCK(hipEventRecord(ws.ev_k0, c.stream));
   ExactWork w{};
   w.pairs = (const ExactPair*)(d_in + in_pairs);
   w.outs = (ExactOut*)d_out;
@@ -425,47 +474,77 @@ int run_exact_chunk(Context& c, Workspace& ws, const PairSpec* specs, size_t beg
   w.recs = (ExactRec*)ws.xrecs.p;
   HIPCK(launch_exact(w, sc, c.stream));
   if (want_trace) HIPCK(launch_walk(w.pairs, w.outs, (uint32_t)n, rpl, sc, c.stream));
-  HIPCK(hipEventRecord(c.ev3, c.stream));
+  HIPCK(hipEventRecord(ws.ev_k1, c.stream));
   // small submissions fetch results and ops in ONE copy (the ops capacity is Q + T per pair); big ones fetch the
-  // results first and then only the op bytes the walkers wrote
-  const bool one_copy = want_trace && out_bytes <= ((size_t)4 << 20);
+  // results first and then only the op bytes the walkers wrote (or, full_copy, the whole region right away)
+  full_copy = full_copy && want_trace && ops_bytes;
+  const bool one_copy = !full_copy && want_trace && out_bytes <= ((size_t)4 << 20);
   const size_t first_bytes = one_copy ? out_bytes : n * sizeof(ExactOut);
   if ((rc = ws.h_out.ensure(first_bytes))) return rc;
   HIPCK(hipMemcpyAsync(ws.h_out.p, d_out, first_bytes, hipMemcpyDeviceToHost, c.stream));
-  HIPCK(hipStreamSynchronize(c.stream));
+  if (full_copy) {  // (the arena is page-locked memory: the copy lands in place)
+    job.arena_base = arena->size();
+    arena->resize(job.arena_base + ops_bytes);
+    HIPCK(hipMemcpyAsync(arena->data() + job.arena_base, d_out + out_ops, ops_bytes, hipMemcpyDeviceToHost, c.stream));
+  }
+  HIPCK(hipEventRecord(ws.ev_done, c.stream));
+  drain.dismiss();
+  job.out_ops = out_ops;
+  job.ops_bytes = ops_bytes;
+  job.want_trace = want_trace;
+  job.one_copy = one_copy;
+  job.full_copy = full_copy;
+  job.d_out = d_out;
+  job.specs = specs;
+  job.arena = arena;
+  tm.lap("  chunk: queue");
+  return SW_OK;
+}
+
+// Waits for the submission and turns its records into PairOuts.
+int exact_chunk_end(Context& c, Workspace& ws, ChunkJob& job, PairOut* outs) {
+  const size_t n = job.n, begin = job.begin;
+  if (n == 0) return SW_OK;
+  StageTimer tm(n);
+  StreamDrain drain(c.stream);  // (an error below must not leave this submission's copies in flight)
+  HIPCK(hipEventSynchronize(ws.ev_done));
+  const bool want_trace = job.want_trace;
+  const size_t out_ops = job.out_ops, ops_bytes = job.ops_bytes;
+  uint8_t* const d_out = job.d_out;
+  OpsArena* const arena = job.arena;
+  const PairSpec* const specs = job.specs;
+  auto& hp = ws.xh.hp;
   const ExactOut* ho = (const ExactOut*)ws.h_out.p;
   tm.lap("  chunk: gpu");
   for (size_t i = 0; i < n; i++)
     if (ho[i].nops == 0xffffffffu) return fail(SW_E_HIP, "exact kernel: strip pipeline wait timed out");
   float ms = 0;
-  HIPCK(hipEventElapsedTime(&ms, c.ev2, c.ev3));
+  HIPCK(hipEventElapsedTime(&ms, ws.ev_k0, ws.ev_k1));
   c.stats.exact_kernel_ms += ms;
-  size_t arena_base = 0;
-  if (want_trace && ops_bytes) {
+  size_t arena_base = job.arena_base;
+  if (want_trace && ops_bytes && !job.full_copy) {
     arena_base = arena->size();
     arena->resize(arena_base + ops_bytes);
     uint8_t* hops = arena->data() + arena_base;
-    if (one_copy) {
+    if (job.one_copy) {
       for (size_t i = 0; i < n; i++) {
         const size_t s0 = (size_t)(hp[i].ops - (d_out + out_ops));
         if (ho[i].nops) memcpy(hops + s0, (const uint8_t*)ws.h_out.p + out_ops + s0, ho[i].nops);
       }
     } else {
-      size_t lo = 0;
-      while (lo < n) {  // coalesce into a few large copies: ops buffers are contiguous per pair
-        size_t hi = lo;
-        size_t start = (size_t)(hp[lo].ops - (d_out + out_ops));
-        size_t endb = start;
-        while (hi < n) {
-          size_t s0 = (size_t)(hp[hi].ops - (d_out + out_ops));
-          if (s0 - endb > (1u << 16)) break;
-          endb = s0 + ho[hi].nops;
-          hi++;
+      // the op bytes the walkers wrote: ONE copy of the span they cover (the arena is page-locked memory: the copy
+      // lands in place)
+      size_t span_lo = SIZE_MAX, span_hi = 0;
+      for (size_t i = 0; i < n; i++)
+        if (ho[i].nops) {
+          const size_t s0 = (size_t)(hp[i].ops - (d_out + out_ops));
+          span_lo = std::min(span_lo, s0);
+          span_hi = std::max(span_hi, s0 + ho[i].nops);
         }
-        if (endb > start) HIPCK(hipMemcpyAsync(hops + start, d_out + out_ops + start, endb - start, hipMemcpyDeviceToHost, c.stream));
-        lo = hi;
+      if (span_hi > span_lo) {
+        HIPCK(hipMemcpyAsync(hops + span_lo, d_out + out_ops + span_lo, span_hi - span_lo, hipMemcpyDeviceToHost, c.stream));
+        HIPCK(hipStreamSynchronize(c.stream));
       }
-      HIPCK(hipStreamSynchronize(c.stream));
     }
   }
   for (size_t i = 0; i < n; i++) {
@@ -483,8 +562,25 @@ int run_exact_chunk(Context& c, Workspace& ws, const PairSpec* specs, size_t beg
       o.nops = ho[i].nops;
     }
   }
+  drain.dismiss();  // nothing of this submission is queued any more (another one may be: not ours to wait for)
   tm.lap("  chunk: results");
   return SW_OK;
+}
+
+int run_exact_chunk(Context& c, Workspace& ws, const PairSpec* specs, size_t begin, size_t end, Scoring sc,
+                    bool want_trace, PairOut* outs, OpsArena* arena, int rpl) {
+  ChunkJob job;
+  const int rc = exact_chunk_begin(c, ws, specs, begin, end, sc, want_trace, arena, rpl, false, job);
+  if (rc) return rc;
+  return exact_chunk_end(c, ws, job, outs);
+}
+
+// bytes of device scratch one pair needs (the split of a submission into chunks goes by it)
+size_t exact_pair_bytes(const PairSpec& sp, int rpl, bool want_trace) {
+  const PathParams pp = resolve_path(sp.path, sp.Q, sp.T);
+  size_t b = (size_t)sp.Q * 2 + (size_t)sp.T * 2 + (size_t)std::max<uint32_t>(exact_nstrips(sp.Q, rpl), 1) * (sp.T + 2) * 4 + 256;
+  if (want_trace) b += exact_dir_words(sp.Q, std::max(pp.Tlim, pp.T0), rpl) * 4 + sp.Q + sp.T;
+  return b;
 }
 
 // Rows per lane for a submission.  4 does the least work per cell and is used whenever the submission fills the
@@ -521,16 +617,13 @@ int exact_choose_rpl(const PairSpec* specs, size_t n, int simds) {
 }  // namespace
 
 int swhip::run_exact(Context& c, Workspace& ws, const PairSpec* specs, size_t n, Scoring sc, bool want_trace,
-                     PairOut* outs, std::vector<uint8_t>* arena) {
+                     PairOut* outs, OpsArena* arena) {
   const int rpl = exact_choose_rpl(specs, n, c.cus * 4);
   size_t begin = 0;
   while (begin < n) {
     size_t end = begin, bytes = 0;
     while (end < n) {
-      PathParams pp = resolve_path(specs[end].path, specs[end].Q, specs[end].T);
-      size_t b = (size_t)specs[end].Q * 2 + (size_t)specs[end].T * 2 +
-                 (size_t)std::max<uint32_t>(exact_nstrips(specs[end].Q, rpl), 1) * (specs[end].T + 2) * 4 + 256;
-      if (want_trace) b += exact_dir_words(specs[end].Q, std::max(pp.Tlim, pp.T0), rpl) * 4 + specs[end].Q + specs[end].T;
+      const size_t b = exact_pair_bytes(specs[end], rpl, want_trace);
       if (end > begin && (bytes + b > c.scratch_budget || end - begin >= (1u << 20))) break;
       bytes += b;
       end++;
@@ -544,6 +637,78 @@ int swhip::run_exact(Context& c, Workspace& ws, const PairSpec* specs, size_t n,
 
 
 namespace {
+// Sub-batches [cut[b], cut[b + 1]) of one submission, two in flight: while sub-batch b is on the GPU, b + 1 is
+// staged and queued behind it (second workspace), and ready(b, rc) -- called in order, once per sub-batch, also
+// after a failure -- lets the caller work on b's results while b + 1 runs.  Tracebacks land in arenas[b].  Caller
+// holds the context mutex for the whole call.
+template <class Ready>
+int run_exact_pipelined(Context& c, const PairSpec* specs, const std::vector<size_t>& cut, Scoring sc, PairOut* outs,
+                        const std::vector<OpsArena*>& arenas, Ready&& ready) {
+  const size_t B = cut.size() - 1;
+  const int rpl = exact_choose_rpl(specs, cut[B], c.cus * 4);
+  Workspace* wss[2] = {&c.ws, &c.ws2};
+  ChunkJob jobs[2];
+  StreamDrain drain(c.stream);
+  int rc = exact_chunk_begin(c, *wss[0], specs, cut[0], cut[1], sc, true, arenas[0], rpl, true, jobs[0]);
+  size_t reported = 0;
+  for (size_t b = 0; b < B && !rc; b++) {
+    int rc_next = SW_OK;
+    if (b + 1 < B)
+      rc_next = exact_chunk_begin(c, *wss[(b + 1) & 1], specs, cut[b + 1], cut[b + 2], sc, true, arenas[b + 1], rpl, true,
+                                  jobs[(b + 1) & 1]);
+    rc = exact_chunk_end(c, *wss[b & 1], jobs[b & 1], outs);
+    ready(b, rc);
+    reported = b + 1;
+    if (!rc) rc = rc_next;
+  }
+  for (size_t bb = reported; bb < B; bb++) ready(bb, rc);  // (only after a failure)
+  return rc;  // (the drain above waits for whatever a failure left queued)
+}
+}  // namespace
+
+// ---- the pool behind ArenaLease -------------------------------------------------------------------------------
+namespace {
+constexpr size_t kArenaPoolSlots = 4, kArenaKeepMax = (size_t)256 << 20;
+std::mutex g_arena_mu;
+// (never destroyed: its blocks are page-locked memory of the HIP runtime, which may be gone at static destruction)
+std::vector<OpsArena>& arena_pool() {
+  static std::vector<OpsArena>* pool = new std::vector<OpsArena>();
+  return *pool;
+}
+}  // namespace
+void swhip::ExactHost::trim() {
+  constexpr size_t kKeep = (size_t)1 << 18;  // pairs (~30 MB of tables)
+  if (hp.capacity() <= kKeep && unit_pair.capacity() <= 4 * kKeep) return;
+  decltype(hp)().swap(hp);
+  decltype(qoff)().swap(qoff);
+  decltype(toff)().swap(toff);
+  decltype(dirw)().swap(dirw);
+  std::vector<uint32_t>().swap(unit_pair);
+  std::vector<uint32_t>().swap(unit_order);
+}
+swhip::ArenaLease::ArenaLease() {
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  std::vector<OpsArena>& pool = arena_pool();
+  if (!pool.empty()) {  // the largest one: a worker's packages are of a kind
+    size_t best = 0;
+    for (size_t i = 1; i < pool.size(); i++)
+      if (pool[i].capacity() > pool[best].capacity()) best = i;
+    a.swap(pool[best]);
+    pool.erase(pool.begin() + (std::ptrdiff_t)best);
+  }
+}
+swhip::ArenaLease::~ArenaLease() {
+  a.clear();
+  if (a.capacity() == 0 || a.capacity() > kArenaKeepMax) return;
+  try {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    std::vector<OpsArena>& pool = arena_pool();
+    if (pool.size() < kArenaPoolSlots) pool.emplace_back(std::move(a));
+  } catch (...) {
+  }
+}
+
+namespace {
 // ---- Result boxes ------------------------------------------------------------------------------------------
 // A batch (sw_align_batch / sw_execute_work: 10^5 results at a time) allocates ONE block, a slab, for all its boxes
 // and strings instead of three heap blocks per result; the slab counts its live parts (a box and each of its two
@@ -551,6 +716,7 @@ namespace {
 // contract.  A result of the one-pair entry points has no slab.
 struct Slab {
   std::atomic<uint64_t> refs;
+  size_t capacity;  // bytes of the block
 };
 struct ResultBox {
   Result r;
@@ -559,8 +725,46 @@ struct ResultBox {
   Slab* slab;  // nullptr: box and strings are heap blocks of their own
 };
 constexpr uint32_t kMagic = 0x53574850u;  // "SWHP"
+// A worker produces one slab per work package and frees it before the next one arrives; a block of tens of
+// megabytes goes back to the kernel on free() and comes back as fresh zero pages (one page fault per 4 KiB while the
+// strings are written).  The last few released slabs are therefore kept for the next batch of a similar size: at
+// most kSlabCacheSlots blocks of at most kSlabCacheMax bytes each stay allocated (SW_HIP_NO_SLAB_CACHE=1: none).
+constexpr size_t kSlabCacheSlots = 4, kSlabCacheMin = (size_t)1 << 20, kSlabCacheMax = (size_t)256 << 20;
+std::atomic<Slab*> g_slab_cache[kSlabCacheSlots];
+bool slab_cache_enabled() {
+  static const bool on = getenv("SW_HIP_NO_SLAB_CACHE") == nullptr;
+  return on;
+}
+Slab* slab_alloc(size_t bytes) {
+  if (bytes >= kSlabCacheMin && bytes <= kSlabCacheMax && slab_cache_enabled()) {
+    for (auto& slot : g_slab_cache) {
+      Slab* s = slot.exchange(nullptr, std::memory_order_acq_rel);
+      if (!s) continue;
+      if (s->capacity >= bytes && s->capacity / 2 <= bytes) return s;
+      Slab* expected = nullptr;  // not a fit: put it back (or drop it if the slot was taken meanwhile)
+      if (!slot.compare_exchange_strong(expected, s, std::memory_order_acq_rel)) free(s);
+    }
+  }
+  const size_t cap = bytes + bytes / 8;  // (a package of the same shape next time fits although its strings differ)
+  Slab* s = (Slab*)malloc(cap);
+  if (s) s->capacity = cap;
+  return s;
+}
+void slab_free(Slab* s) {
+  if (s->capacity >= kSlabCacheMin && s->capacity <= kSlabCacheMax + kSlabCacheMax / 8 && slab_cache_enabled()) {
+    for (auto& slot : g_slab_cache) {
+      Slab* expected = nullptr;
+      if (slot.compare_exchange_strong(expected, s, std::memory_order_acq_rel)) return;
+    }
+    // all slots taken: replace the first (the oldest habits of the caller change slowly; any policy does)
+    Slab* old = g_slab_cache[0].exchange(s, std::memory_order_acq_rel);
+    if (old) free(old);
+    return;
+  }
+  free(s);
+}
 void slab_release(Slab* s, uint64_t n) {
-  if (s->refs.fetch_sub(n, std::memory_order_acq_rel) == n) free(s);
+  if (s->refs.fetch_sub(n, std::memory_order_acq_rel) == n) slab_free(s);
 }
 // Result strings carry a 16-byte header in front of the characters: which Result (if any) still owns them.  That
 // is what lets free_c_string() be called on either string of a Result before free_alignment_result()
@@ -742,8 +946,6 @@ int swhip::align_many_on(int device, const char* const* queries, const char* con
   if (n == 0) return SW_OK;
   StageTimer tm(n);
   if (!queries || !targets || !out) return fail(SW_E_ARG, "null argument");
-  if (path < 0 || path > 2) return fail(SW_E_ARG, "bad path");
-  const Scoring sc = to_scoring(as);
   // A work package names the same sequences over and over (worker_impl.go:115-117): decode each distinct input
   // pointer once.
   std::unordered_map<const char*, uint32_t> seen;
@@ -759,19 +961,49 @@ int swhip::align_many_on(int device, const char* const* queries, const char* con
     return id;
   };
   for (size_t i = 0; i < n; i++) {
-    out[i] = nullptr;
     qi[i] = intern(queries[i]);
     ti[i] = intern(targets[i]);
   }
   tm.lap("intern");
-  std::vector<Decoded> dec(distinct.size());
-  std::vector<uint8_t> ok(distinct.size(), 0);
-  std::vector<size_t> lens(distinct.size());
+  return align_interned(device, distinct.data(), distinct.size(), qi.data(), ti.data(), n, as, path, out);
+}
+
+int swhip::align_interned(int device, const char* const* distinct_p, size_t n_distinct, const uint32_t* qi,
+                          const uint32_t* ti, size_t n, AlignmentScores as, int path, Result** out) {
+  if (n == 0) return SW_OK;
+  StageTimer tm(n);
+  if (!distinct_p || !qi || !ti || !out) return fail(SW_E_ARG, "null argument");
+  if (path < 0 || path > 2) return fail(SW_E_ARG, "bad path");
+  const Scoring sc = to_scoring(as);
+  // only the sequences some pair names are decoded (a package may carry more)
+  std::vector<uint8_t> used(n_distinct, 0);
+  for (size_t i = 0; i < n; i++) {
+    out[i] = nullptr;
+    if (qi[i] != UINT32_MAX) {
+      if (qi[i] >= n_distinct) return fail(SW_E_ARG, "sequence index out of range");
+      used[qi[i]] = 1;
+    }
+    if (ti[i] != UINT32_MAX) {
+      if (ti[i] >= n_distinct) return fail(SW_E_ARG, "sequence index out of range");
+      used[ti[i]] = 1;
+    }
+  }
+  std::vector<Decoded> dec(n_distinct);
+  std::vector<uint8_t> ok(n_distinct, 0);
+  std::vector<size_t> lens(n_distinct, 0);
   size_t total_bytes = 0;
-  for (size_t d = 0; d < distinct.size(); d++) total_bytes += (lens[d] = strlen(distinct[d]));
-  parallel_ranges(distinct.size(), total_bytes, [&](size_t lo, size_t hi) {
+  std::vector<size_t> sym_at(n_distinct, 0);
+  for (size_t d = 0; d < n_distinct; d++)
+    if (used[d] && distinct_p[d]) {
+      sym_at[d] = total_bytes;
+      total_bytes += (lens[d] = strlen(distinct_p[d]));
+    }
+  // one pool for the symbols of all sequences (a sequence has at most as many symbols as bytes)
+  std::vector<uint16_t, NoInitAlloc<uint16_t>> sym_pool(total_bytes + 1);
+  for (size_t d = 0; d < n_distinct; d++) dec[d].sym.bind(sym_pool.data() + sym_at[d]);
+  parallel_ranges(n_distinct, total_bytes, [&](size_t lo, size_t hi) {
     for (size_t d = lo; d < hi; d++)  // bindings.rs:125 unwrap: invalid UTF-8 -> NULL
-      ok[d] = decode(distinct[d], lens[d], dec[d]) && dec[d].sym.size() < 0x7fffff00u;
+      ok[d] = used[d] && distinct_p[d] && decode(distinct_p[d], lens[d], dec[d]) && dec[d].sym.size() < 0x7fffff00u;
   });
   tm.lap("decode");
   std::vector<PairSpec> specs;
@@ -786,7 +1018,8 @@ int swhip::align_many_on(int device, const char* const* queries, const char* con
     idx.push_back(i);
   }
   std::vector<PairOut> po(specs.size());
-  std::vector<uint8_t> arena;
+  ArenaLease lease;
+  OpsArena& arena = lease.a;
   tm.lap("specs");
   // The work-package fast path (sw_package.cpp) takes the pairs it is eligible for: long ACGT targets on the ring
   // path, filled by the packed score kernel and traced inside windows.  Same results, by construction and by test.
@@ -798,15 +1031,174 @@ int swhip::align_many_on(int device, const char* const* queries, const char* con
     if (rc) return rc;
     tm.lap("windows");
   }
-  {
+  // Results of pairs [k_lo, k_hi) as ONE slab: [Slab | ResultBox x pairs | per pair: StrHdr + query alignment + NUL,
+  // StrHdr + target alignment + NUL].  ASCII pairs (the normal case) know their string lengths up front (= the
+  // number of traceback ops); a pair with non-ASCII symbols re-encodes to UTF-8 and keeps heap strings of its own.
+  auto emit = [&](size_t k_lo, size_t k_hi, const OpsArena& ar) -> int {
+    if (k_hi <= k_lo) return SW_OK;
+    const size_t m = k_hi - k_lo;
+    auto round8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
+    std::vector<size_t> str_off(m + 1, 0);
+    const size_t boxes_off = round8(sizeof(Slab));
+    size_t bytes = boxes_off + m * sizeof(ResultBox);
+    for (size_t k = k_lo; k < k_hi; k++) {
+      const size_t i = idx[k];
+      str_off[k - k_lo] = bytes;
+      if (dec[qi[i]].ascii && dec[ti[i]].ascii) bytes += 2 * (sizeof(StrHdr) + round8((size_t)po[k].nops + 1));
+    }
+    str_off[m] = bytes;
+    Slab* slab = slab_alloc(bytes);
+    if (!slab) return fail(SW_E_NOMEM, "out of host memory");
+    new (&slab->refs) std::atomic<uint64_t>(0);
+    ResultBox* boxes = (ResultBox*)((char*)slab + boxes_off);
+    std::atomic<uint64_t> live{0};
+    parallel_ranges(m, ar.size() * 4 + m * 64, [&](size_t lo, size_t hi) {
+      uint64_t mine = 0;
+      for (size_t kk = lo; kk < hi; kk++) {
+        const size_t k = k_lo + kk, i = idx[k];
+        ResultBox* b = boxes + kk;
+        memset(b, 0, sizeof(ResultBox));
+        const Decoded &q = dec[qi[i]], &t = dec[ti[i]];
+        const PairOut& o = po[k];
+        const uint8_t* ops = ar.data() + o.ops_off;
+        if (q.ascii && t.ascii) {
+          const size_t each = sizeof(StrHdr) + round8((size_t)o.nops + 1);
+          StrHdr* hq = (StrHdr*)((char*)slab + str_off[kk]);
+          StrHdr* ht = (StrHdr*)((char*)slab + str_off[kk] + each);
+          hq->magic = ht->magic = kStrMagicSlab;
+          char *qa = (char*)(hq + 1), *ta = (char*)(ht + 1);
+          uint32_t nx = 0, nj = 0;
+          for (uint32_t c = 0; c < o.nops; c++) {
+            nx += ops[c] != 2;
+            nj += ops[c] != 1;
+          }
+          uint32_t cx = o.bx - nx, cj = o.bj - nj;  // 0-based index of the first aligned symbol
+          size_t w = 0;
+          for (uint32_t c = o.nops; c-- > 0; w++) {
+            const uint8_t op = ops[c];
+            qa[w] = op == 2 ? '-' : q.src[cx++];
+            ta[w] = op == 1 ? '-' : t.src[cj++];
+          }
+          qa[w] = ta[w] = 0;
+          b->slab = slab;
+          box_fill(b, qa, ta, path, o);
+          mine += 3;
+        } else {
+          char *qa = nullptr, *ta = nullptr;
+          size_t qlen = 0;
+          if (!build_alignment(q, t, o, ops, &qa, &ta, &qlen)) continue;  // (out of memory: the pair reads as failed)
+          b->slab = slab;
+          box_fill(b, qa, ta, path, o);
+          mine += 1;  // the box only: its strings are heap blocks
+        }
+        out[i] = &b->r;
+      }
+      live.fetch_add(mine);
+    });
+    if (live.load() == 0) slab_free(slab);
+    else slab->refs.store(live.load(), std::memory_order_release);
+    return SW_OK;
+  };
+
+  size_t n_handled = 0;
+  for (uint8_t h_ : handled) n_handled += h_ != 0;
+  // A whole work package of short pairs: cut into a few sub-batches so that the result strings of one are assembled
+  // (here) while the next is on the GPU (a second host thread drives it).  One slab per sub-batch.
+  size_t scratch_est = 0;  // generous bound of the device scratch the pairs need together (direction bits dominate)
+  for (const PairSpec& sp : specs) scratch_est += (size_t)sp.Q * sp.T / 3 + 16 * ((size_t)sp.Q + sp.T) + 4096;
+  if (n_handled == 0 && specs.size() >= 32768 && scratch_est <= ((size_t)3 << 30)) {
+    const size_t B = std::min<size_t>(8, std::max<size_t>(2, specs.size() / 25000));
+    struct Part {
+      ArenaLease lease;
+      int rc = SW_OK;
+      bool done = false;
+      std::string err;
+    };
+    std::vector<Part> parts(B);
+    std::mutex mu;
+    std::condition_variable cv;
+    auto lo_of = [&](size_t b) { return specs.size() * b / B; };
+    auto produce = [&]() noexcept {
+      std::vector<size_t> cut(B + 1);
+      std::vector<OpsArena*> arenas(B);
+      for (size_t b = 0; b <= B; b++) cut[b] = lo_of(b);
+      for (size_t b = 0; b < B; b++) arenas[b] = &parts[b].lease.a;
+      auto ready = [&](size_t b, int rc) {
+        std::string err;
+        if (rc) {
+          try {
+            err = last_error_string();
+          } catch (...) {
+          }
+        }
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          parts[b].rc = rc;
+          parts[b].err.swap(err);
+          parts[b].done = true;
+        }
+        cv.notify_all();
+      };
+      size_t told = 0;
+      const int rc = guarded<int>(SW_E_NOMEM, [&]() -> int {
+        CtxLock L(device);
+        if (L.rc) return L.rc;
+        return run_exact_pipelined(*L.c, specs.data(), cut, sc, po.data(), arenas, [&](size_t b, int r) {
+          ready(b, r);
+          told = b + 1;
+        });
+      });
+      for (size_t b = told; b < B; b++) ready(b, rc ? rc : SW_E_HIP);  // (lock failure or an exception: nothing ran)
+    };
+    std::thread producer;
+    bool threaded = true;
+    try {
+      producer = std::thread(produce);
+    } catch (...) {
+      threaded = false;
+    }
+    if (threaded) {
+      int rc = SW_OK;
+      std::string err;
+      for (size_t b = 0; b < B; b++) {
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return parts[b].done; });
+        }
+        if (rc) continue;  // (drain: the producer marks the remaining parts done)
+        if (parts[b].rc) {
+          rc = parts[b].rc;
+          err = parts[b].err;
+          continue;
+        }
+        const int erc = guarded<int>(SW_E_NOMEM, [&] { return emit(lo_of(b), lo_of(b + 1), parts[b].lease.a); });
+        if (erc) {
+          rc = erc;
+          err = last_error_string();
+        }
+      }
+      producer.join();
+      tm.lap("run_exact + strings (pipelined)");
+      return rc ? fail(rc, err) : SW_OK;
+    }
+    // (no thread to be had: the plain path below)
+  }
+  if (n_handled == 0 && !specs.empty()) {  // no copies
+    CtxLock L(device);
+    if (L.rc) return L.rc;
+    const int rc = run_exact(*L.c, L.c->ws, specs.data(), specs.size(), sc, true, po.data(), &arena);
+    if (rc) return rc;
+  } else if (n_handled < specs.size()) {
     std::vector<PairSpec> rest;
     std::vector<size_t> rest_k;
+    rest.reserve(specs.size() - n_handled);
+    rest_k.reserve(specs.size() - n_handled);
     for (size_t k = 0; k < specs.size(); k++)
       if (!handled[k]) {
         rest.push_back(specs[k]);
         rest_k.push_back(k);
       }
-    if (!rest.empty()) {
+    {
       std::vector<PairOut> ro(rest.size());
       CtxLock L(device);
       if (L.rc) return L.rc;
@@ -816,71 +1208,9 @@ int swhip::align_many_on(int device, const char* const* queries, const char* con
     }
   }
   tm.lap("run_exact");
-  // One slab for the whole batch: [Slab | ResultBox x pairs | per pair: StrHdr + query alignment + NUL, StrHdr +
-  // target alignment + NUL].  ASCII pairs (the normal case) know their string lengths up front (= the number of
-  // traceback ops); a pair with non-ASCII symbols re-encodes to UTF-8 and keeps heap strings of its own.
-  auto round8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
-  std::vector<size_t> str_off(specs.size() + 1, 0);
-  const size_t boxes_off = round8(sizeof(Slab));
-  size_t bytes = boxes_off + specs.size() * sizeof(ResultBox);
-  for (size_t k = 0; k < specs.size(); k++) {
-    const size_t i = idx[k];
-    str_off[k] = bytes;
-    if (dec[qi[i]].ascii && dec[ti[i]].ascii) bytes += 2 * (sizeof(StrHdr) + round8((size_t)po[k].nops + 1));
-  }
-  str_off[specs.size()] = bytes;
-  Slab* slab = (Slab*)malloc(bytes);
-  if (!slab) return fail(SW_E_NOMEM, "out of host memory");
-  new (&slab->refs) std::atomic<uint64_t>(0);
-  ResultBox* boxes = (ResultBox*)((char*)slab + boxes_off);
-  std::atomic<uint64_t> live{0};
-  parallel_ranges(specs.size(), arena.size() * 4 + specs.size() * 64, [&](size_t lo, size_t hi) {
-    uint64_t mine = 0;
-    for (size_t k = lo; k < hi; k++) {
-      const size_t i = idx[k];
-      ResultBox* b = boxes + k;
-      memset(b, 0, sizeof(ResultBox));
-      const Decoded &q = dec[qi[i]], &t = dec[ti[i]];
-      const PairOut& o = po[k];
-      const uint8_t* ops = arena.data() + o.ops_off;
-      if (q.ascii && t.ascii) {
-        const size_t each = sizeof(StrHdr) + round8((size_t)o.nops + 1);
-        StrHdr* hq = (StrHdr*)((char*)slab + str_off[k]);
-        StrHdr* ht = (StrHdr*)((char*)slab + str_off[k] + each);
-        hq->magic = ht->magic = kStrMagicSlab;
-        char *qa = (char*)(hq + 1), *ta = (char*)(ht + 1);
-        uint32_t nx = 0, nj = 0;
-        for (uint32_t c = 0; c < o.nops; c++) {
-          nx += ops[c] != 2;
-          nj += ops[c] != 1;
-        }
-        uint32_t cx = o.bx - nx, cj = o.bj - nj;  // 0-based index of the first aligned symbol
-        size_t w = 0;
-        for (uint32_t c = o.nops; c-- > 0; w++) {
-          const uint8_t op = ops[c];
-          qa[w] = op == 2 ? '-' : q.src[cx++];
-          ta[w] = op == 1 ? '-' : t.src[cj++];
-        }
-        qa[w] = ta[w] = 0;
-        b->slab = slab;
-        box_fill(b, qa, ta, path, o);
-        mine += 3;
-      } else {
-        char *qa = nullptr, *ta = nullptr;
-        size_t qlen = 0;
-        if (!build_alignment(q, t, o, ops, &qa, &ta, &qlen)) continue;  // (out of memory: the pair reads as failed)
-        b->slab = slab;
-        box_fill(b, qa, ta, path, o);
-        mine += 1;  // the box only: its strings are heap blocks
-      }
-      out[i] = &b->r;
-    }
-    live.fetch_add(mine);
-  });
-  if (live.load() == 0) free(slab);
-  else slab->refs.store(live.load(), std::memory_order_release);
+  const int erc = emit(0, specs.size(), arena);
   tm.lap("strings");
-  return SW_OK;
+  return erc;
 }
 
 namespace {
@@ -1033,6 +1363,44 @@ void free_alignment_result(Result* result) {
   }
   if (b->slab) slab_release(b->slab, parts);
   else free(b);
+}
+
+// Many results at once (additive, include/sw_hip.h): what free_alignment_result does for each, with one reference
+// count update per run of results that share a slab instead of one per result.
+void sw_free_alignment_results(Result** results, size_t n) {
+  if (!results) return;
+  Slab* cur = nullptr;
+  uint64_t cur_parts = 0;
+  for (size_t i = 0; i < n; i++) {
+    Result* r = results[i];
+    results[i] = nullptr;
+    if (!r) continue;
+    ResultBox* b = (ResultBox*)r;
+    if (b->magic != kMagic) continue;
+    b->magic = 0;
+    uint64_t parts = 1;
+    for (char* sp : {b->r.query_ptr, b->r.target_ptr}) {
+      if (!sp) continue;
+      StrHdr* h = (StrHdr*)sp - 1;
+      if (h->magic == kStrMagicSlab) {
+        h->magic = 0;
+        parts++;
+      } else {
+        str_free(sp);
+      }
+    }
+    if (!b->slab) {
+      free(b);
+      continue;
+    }
+    if (b->slab != cur) {
+      if (cur) slab_release(cur, cur_parts);
+      cur = b->slab;
+      cur_parts = 0;
+    }
+    cur_parts += parts;
+  }
+  if (cur) slab_release(cur, cur_parts);
 }
 
 void free_c_string(char* str) {

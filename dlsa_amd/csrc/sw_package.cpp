@@ -54,7 +54,7 @@ thread_local PackageStats g_package_stats;  // of the calling thread's last batc
 
 int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint32_t>& pair_q,
                          const std::vector<uint32_t>& pair_t, Scoring sc, std::vector<PairOut>& po,
-                         std::vector<uint8_t>& arena, std::vector<uint8_t>& handled, int device) {
+                         OpsArena& arena, std::vector<uint8_t>& handled, int device) {
   const size_t n = pair_q.size();
   handled.assign(n, 0);
   g_package_stats = PackageStats{};
@@ -268,7 +268,8 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
           }
         }
         std::vector<PairOut> outs(wins.size());
-        std::vector<uint8_t> ops_arena;
+        ArenaLease ops_lease;
+        OpsArena& ops_arena = ops_lease.a;
         if ((rc = run_exact(*L.c, L.c->ws, specs.data(), specs.size(), sc, true, outs.data(), &ops_arena))) return rc;
         st.windows += wins.size();
         for (size_t w = 0; w < wins.size(); w++) st.window_cells += (uint64_t)specs[w].Q * specs[w].T;

@@ -82,29 +82,42 @@ static int execute_work(const sw_node* node, const sw_work_package* work, sw_ali
   for (uint64_t i = 0; i < n; i++) todo[i] = i;
   const int chain[3] = {SW_PATH_LOW_MEMORY, SW_PATH_SIMD, SW_PATH_STRAIGHT};
   for (int level = 0; level < 3 && !todo.empty(); level++) {
-    std::vector<const char*> qs(todo.size()), ts(todo.size());
-    for (size_t k = 0; k < todo.size(); k++) {
-      qs[k] = work->sequences[work->pairs[todo[k]].query];
-      ts[k] = work->sequences[work->pairs[todo[k]].target];
-    }
     std::vector<Result*> res(todo.size(), nullptr);
-    const int rc = node ? sw_node_align_batch(node, qs.data(), ts.data(), todo.size(), sc, chain[level], res.data())
-                        : sw_align_batch(qs.data(), ts.data(), todo.size(), sc, chain[level], res.data());
+    int rc;
+    if (node) {
+      std::vector<const char*> qs(todo.size()), ts(todo.size());
+      for (size_t k = 0; k < todo.size(); k++) {
+        qs[k] = work->sequences[work->pairs[todo[k]].query];
+        ts[k] = work->sequences[work->pairs[todo[k]].target];
+      }
+      rc = sw_node_align_batch(node, qs.data(), ts.data(), todo.size(), sc, chain[level], res.data());
+    } else {
+      // the package already names its sequences by index: nothing to re-discover from pointers
+      std::vector<uint32_t> qi(todo.size()), ti(todo.size());
+      for (size_t k = 0; k < todo.size(); k++) qi[k] = work->pairs[todo[k]].query, ti[k] = work->pairs[todo[k]].target;
+      rc = swhip::align_interned(-1, work->sequences, work->n_sequences, qi.data(), ti.data(), todo.size(), sc,
+                                 chain[level], res.data());
+      if (rc != SW_OK)  // nothing is handed over on failure
+        for (Result*& r : res) {
+          free_alignment_result(r);
+          r = nullptr;
+        }
+    }
     if (rc != SW_OK) {
       sw_alignment_details_free(out, n);
       return rc;  // no GPU / HIP failure: nothing can be computed (message already recorded)
     }
     std::vector<uint64_t> failed;
-    bool nomem = false;
+    std::atomic<bool> nomem_flag{false};
+    // (the detail's Length is strlen of a string of the pair's size: 10^5 of them are worth the host threads)
+    swhip::parallel_ranges(todo.size(), todo.size() * 512, [&](size_t lo, size_t hi) {
+      for (size_t k = lo; k < hi; k++)
+        if (res[k] && !fill_detail(out[todo[k]], res[k], chain[level])) nomem_flag.store(true);
+    });
+    const bool nomem = nomem_flag.load();
     for (size_t k = 0; k < todo.size(); k++) {
-      if (!res[k]) {
-        failed.push_back(todo[k]);
-        continue;
-      }
-      if (nomem || !fill_detail(out[todo[k]], res[k], chain[level])) {
-        nomem = true;
-        if (!out[todo[k]].owner_) free_alignment_result(res[k]);
-      }
+      if (!res[k]) failed.push_back(todo[k]);
+      else if (nomem && !out[todo[k]].owner_) free_alignment_result(res[k]);
     }
     if (nomem) {
       sw_alignment_details_free(out, n);
@@ -146,15 +159,31 @@ int sw_node_execute_work(const sw_node* node, const sw_work_package* work, sw_al
 
 void sw_alignment_details_free(sw_alignment_detail* d, uint64_t n) {
   if (!d) return;
-  for (uint64_t i = 0; i < n; i++) {
-    if (d[i].owner_) {
-      free_alignment_result((Result*)d[i].owner_);  // the strings are the Result's
-    } else {
-      free(d[i].query_alignment);
-      free(d[i].target_alignment);
+  // The strings are the Results': freed in runs (one reference-count update per run and slab), on the host threads
+  // when there are 10^5 of them (every result touches three cache lines of a slab of tens of megabytes).
+  auto free_range = [d](size_t lo, size_t hi) {
+    Result* run[256];
+    size_t nrun = 0;
+    for (size_t i = lo; i < hi; i++) {
+      if (d[i].owner_) {
+        run[nrun++] = (Result*)d[i].owner_;
+        if (nrun == 256) {
+          sw_free_alignment_results(run, nrun);
+          nrun = 0;
+        }
+      } else {
+        free(d[i].query_alignment);
+        free(d[i].target_alignment);
+      }
+      d[i].query_alignment = d[i].target_alignment = nullptr;
+      d[i].owner_ = nullptr;
     }
-    d[i].query_alignment = d[i].target_alignment = nullptr;
-    d[i].owner_ = nullptr;
+    sw_free_alignment_results(run, nrun);
+  };
+  try {
+    swhip::parallel_ranges((size_t)n, (size_t)n * 256, free_range);
+  } catch (...) {  // (no threads to be had and the range already partly done: entries already freed are NULL)
+    free_range(0, (size_t)n);
   }
 }
 

@@ -53,6 +53,12 @@ int32_t sw_result_score32(const struct Result *result);
 int sw_align_batch(const char *const *queries, const char *const *targets, size_t n_pairs,
                    struct AlignmentScores scores, int path, struct Result **out);
 
+/* free_alignment_result() for every non-NULL entry of results[0..n) (entries are set to NULL): the results of one
+ * sw_align_batch call share one block of memory, and this releases it with one reference-count update per run of
+ * results instead of one per result.  Mixing it with free_alignment_result / free_c_string on other results of the
+ * same batch is fine. */
+void sw_free_alignment_results(struct Result **results, size_t n);
+
 /* ---- resident target database + top-k: what cli/__main__.py:153-173 computes client-side after every
  * pair's result has travelled worker -> master -> CLI. */
 typedef struct sw_db sw_db;

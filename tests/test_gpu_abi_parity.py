@@ -168,6 +168,44 @@ def test_concurrent_callers(oracle):
         assert (g.query, g.target, g.score, g.max_x, g.max_y) == (e["q"], e["t"], e["score"], e["max_x"], e["max_y"])
 
 
+def test_batch_results_freed_in_any_mix(oracle):
+    """The results of one sw_align_batch call share a slab: every way of freeing them -- one by one, strings first, in
+    bulk (sw_free_alignment_results), or a mix -- releases each exactly once; a later batch of the same shape (which
+    may be handed the recycled slab) still comes out right."""
+    import ctypes as C
+    import dlsa_amd
+    from dlsa_amd import bridge
+    L = bridge.lib()
+    rng = random.Random(12)
+    n = 40000                                            # > 32768 pairs: sub-batches, two in flight, a slab each
+    qs = [_rnd(rng, 40).encode() for _ in range(8)]
+    ts = [_rnd(rng, rng.randint(20, 60)).encode() for _ in range(n)]
+    qarr = (C.c_char_p * n)(*[qs[i % 8] for i in range(n)])
+    tarr = (C.c_char_p * n)(*ts)
+    sc = dlsa_amd.AlignmentScore(2, -1, -1).c()
+    first = None
+    for round_ in range(3):
+        out = (C.POINTER(bridge.CResult) * n)()
+        assert L.sw_align_batch(qarr, tarr, n, sc, 0, out) == 0
+        got = [(C.string_at(out[i].contents.query_ptr), out[i].contents.score) for i in range(0, n, 997)]
+        if first is None:
+            first = got
+            for i in range(0, n, 211):                   # ... and every sub-batch gives the oracle's results
+                r = out[i].contents
+                e = oracle.align("lowmem", qs[i % 8].decode(), ts[i].decode(), -1, 2, -1)
+                assert (C.string_at(r.query_ptr).decode(), C.string_at(r.target_ptr).decode(), r.score, r.max_x, r.max_y) == (
+                    e["q"], e["t"], e["score"] & 0xFFFF, e["max_x"] % 2**64, e["max_y"] % 2**64), i
+        assert got == first
+        for i in range(0, n, 3):                         # a third the reference's way: one call per result,
+            if i % 2:
+                L.free_c_string(out[i].contents.target_ptr)   # some with a string freed first
+            L.free_alignment_result(out[i])
+            out[i] = None
+        L.sw_free_alignment_results(out, n)              # the rest in bulk (NULL entries are skipped)
+        assert all(not out[i] for i in range(n))
+        L.sw_free_alignment_results(out, n)              # and again: nothing left to free
+
+
 def test_align_batch_matches_single_calls(oracle):
     import dlsa_amd
     from dlsa_amd import bridge
