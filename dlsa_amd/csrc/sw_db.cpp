@@ -417,7 +417,13 @@ int64_t build_units_raw(const ScoreGroup* groups, size_t ng, uint32_t n_elems, u
   size_t n_lanes = 0;
   const uint64_t approx_units = ((uint64_t)n_elems + W - 1) / W;
   const uint64_t Lmin = std::min<uint64_t>(32, std::max<uint64_t>(2, approx_units / (4ull * S)));
-  const uint64_t Lmax = 4 * Lmin + 16;
+  // A lane is a chain of dependent units: with fewer lanes than resident workgroups a unit's predecessor is still
+  // running when the unit starts, and its wave 0 waits for the first published blocks at every unit.  Lanes are
+  // therefore no longer than it takes to have about one lane per workgroup; within that, the cut that fills the
+  // last unit best wins.  (Measured, 10 kb query: 65-strip groups 80.1 -> 78.4 ms, 33-strip groups 83.8 -> 80.8 ms;
+  // lanes of 16 groups of 63 strips, which would fill every unit, cost +8 %.)
+  uint64_t Lmax = std::min<uint64_t>(4 * Lmin + 16, std::max<uint64_t>(Lmin + 2, approx_units / std::max<uint32_t>(max_wg, 1)));
+  if (const char* e = getenv("SW_HIP_SCORE_LMAX")) Lmax = std::max(1, atoi(e));  // experiments
   for (size_t g = 0; g < ng;) {
     uint64_t cum = 0;
     size_t best = g;
