@@ -443,7 +443,7 @@ int64_t build_units_raw(const ScoreGroup* groups, size_t ng, uint32_t n_elems, u
   uint32_t full = UINT32_MAX, Wtail = W;
   size_t n_units = 0;
   uint64_t chained = 0;
-  for (int pass = 0; pass < 2; pass++) {
+  for (int pass = 0; pass < 3; pass++) {
     for (size_t l = 0; l < n_lanes; l++) lanes[l].pos = lanes[l].start, lanes[l].last_ticket = UINT32_MAX;
     n_units = 0;
     chained = 0;
@@ -479,10 +479,23 @@ int64_t build_units_raw(const ScoreGroup* groups, size_t ng, uint32_t n_elems, u
     if (pass == 0) {
       const uint32_t n = (uint32_t)n_units;
       const uint32_t r = max_wg ? n % max_wg : 0;
-      const uint32_t f = r ? std::min<uint32_t>(4, max_wg / r) : 0;
-      if (n <= max_wg || f < 2 || W < 8) break;  // no partial round worth cutting
+      if (n <= max_wg || r == 0 || W < 8) break;  // no partial round worth cutting
+      const uint32_t f = std::min<uint32_t>(4, max_wg / r);
+      if (f >= 2) {
+        Wtail = W / f;
+      } else {
+        // more than half a round left: units of 3/4 the strips (3 waves per SIMD instead of 4) if they still fit
+        // one round -- every workgroup then works for about 3/4 of a unit time instead of some for a whole one
+        const uint32_t c = (uint32_t)((((uint64_t)r * W + max_wg - 1) / max_wg + 3) & ~(uint64_t)3);
+        if (c >= W) break;
+        Wtail = c;
+      }
       full = n - r;
-      Wtail = W / f;
+    } else if (pass == 1) {
+      // the short units must fit ONE round (lane ends add partial units): otherwise back to full units
+      if (full == UINT32_MAX || n_units - full <= max_wg) break;
+      full = UINT32_MAX;
+      Wtail = W;
     }
   }
   // units whose last strip is not the last strip of its group hand their H column to the next unit through HBM
