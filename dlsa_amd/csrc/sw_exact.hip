@@ -376,6 +376,8 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
     int within = (int)((bx - 1) % SH);
     int jm1 = (int)bj - 1;
     bool go = true;
+    bool tile_mode = false;    // how the path is followed inside a window: diagonal runs (below) or 7 x 7 tiles
+    uint32_t diag_tiles = 0;
     while (go) {
       // ---- stage a window: blocks [wbase, wtop] of this strip; all loads in flight before the first LDS write
       const uint32_t ktop = (uint32_t)jm1 + ((uint32_t)within >> LOG_RPL);
@@ -421,6 +423,74 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
       for (;;) {
         const int k0 = jm1 + (within >> LOG_RPL);
         if (k0 < wlo) break;  // window exhausted (same strip)
+        if (tile_mode) {
+          // ---- a 7 x 7 TILE of cells up-left of the current one: lane (dr, dc) = (lane / 8, lane % 8) holds the code
+          // of cell (row - dr, col - dc); row 7 and column 7 of the lane grid are sentinels (never valid).  The path
+          // through the tile is followed on the scalar unit over the ballots of the two code bits -- every move
+          // adds 9 (diagonal), 8 (up) or 1 (left) to the lane index, so path order is lane order -- and the H
+          // bookkeeping of all its moves is done at once afterwards (prefix counts over the path mask).  Alignments
+          // of unrelated sequences change direction every two or three cells: this follows ~10 moves per LDS round
+          // trip where the diagonal-run iteration below follows ~3.
+          const int dr = (int)(lane >> 3), dc = (int)(lane & 7u);
+          const int wr = within - dr, jt = jm1 - dc;
+          const int kt = jt + (wr >> LOG_RPL);
+          const bool valid = dr < 7 && dc < 7 && wr >= 0 && jt >= 0 && kt >= wlo;
+          uint32_t code = 0;
+          bool eq = false;
+          if (valid) {
+            const uint32_t w = wdir[(((uint32_t)kt >> 4) - wbase) * SH + (uint32_t)wr];
+            code = (w >> ((~(uint32_t)kt & 15u) * 2)) & 3u;
+            eq = wq[wr] == wt[jt - tbase];
+          }
+          const uint64_t V = __builtin_amdgcn_ballot_w64(valid);
+          const uint64_t Dm = __builtin_amdgcn_ballot_w64(valid && (code & 1u));
+          const uint64_t Um = __builtin_amdgcn_ballot_w64(valid && (code & 2u));
+          const uint64_t EQ = __builtin_amdgcn_ballot_w64(eq);
+          uint64_t PM = 0;
+          for (uint32_t idx = 0; (V >> idx) & 1ull;) {  // (V has no bit in row 7 / column 7: idx stays below 64)
+            PM |= 1ull << idx;
+            idx += ((Dm >> idx) & 1ull) ? 9u : (((Um >> idx) & 1ull) ? 8u : 1u);
+          }
+          const uint64_t me = 1ull << lane;
+          const bool isd = (Dm & me) != 0, isu = !isd && (Um & me) != 0;
+          const uint64_t PD = PM & Dm, PE = PD & EQ, PG = PM & ~Dm;
+          auto upto = [&](uint64_t m) -> int {  // bits of m in lanes <= mine
+            return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) + ((m & me) ? 1 : 0);
+          };
+          const int ne = upto(PE), nd_ = upto(PD), ng = upto(PG);
+          const int h_after = H - match * ne - miss * (nd_ - ne) - gap * ng;  // H after this lane's move (path lanes)
+          const uint64_t stop = __builtin_amdgcn_ballot_w64((PM & me) && h_after <= 0);
+          const uint64_t T = stop ? (PM & ((2ull << __builtin_ctzll(stop)) - 1ull)) : PM;  // the moves taken
+          const uint32_t lt = 63u - (uint32_t)__builtin_clzll(T);                        // lane of the last one (T != 0)
+          uint32_t n = (uint32_t)__builtin_popcountll(T);
+          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(T >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)T, 0u));
+          if (nops + n > cap) n = cap - nops;
+          if ((T & me) && rank < n) P.ops[nops + rank] = (uint8_t)(isd ? 0u : (isu ? 1u : 2u));
+          nops += n;
+          const int moved = (dr + ((isd || isu) ? 1 : 0)) | ((dc + ((isd || !isu) ? 1 : 0)) << 8);
+          const int mv = __builtin_amdgcn_readlane(moved, (int)lt);
+          H = __builtin_amdgcn_readlane(h_after, (int)lt);
+          within -= mv & 0xff;
+          jm1 -= mv >> 8;
+          // back to diagonal runs once two tiles in a row were crossed corner to corner
+          diag_tiles = ((T & ~Dm) == 0 && n >= 7) ? diag_tiles + 1 : 0;
+          if (diag_tiles >= 2) tile_mode = false;
+          if (H <= 0 || jm1 < 0 || nops >= cap) {
+            go = false;
+            break;
+          }
+          if (within < 0) {  // into the strip above (or off the top edge)
+            if (strip == 0) {
+              go = false;
+              within = -1;  // row 0
+              break;
+            }
+            strip--;
+            within += SH;
+            break;
+          }
+          continue;
+        }
         const int wr = within - (int)lane, jt = jm1 - (int)lane;
         const int kt = jt + (wr >> LOG_RPL);
         const bool valid = wr >= 0 && jt >= 0 && kt >= wlo;
@@ -454,6 +524,10 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
         if (nops + n > cap) n = cap - nops;
         if (lane < n) P.ops[nops + lane] = (uint8_t)op;
         nops += n;
+        if (nd < 4 && take_gap) {  // direction changes every few cells: follow the path tile by tile
+          tile_mode = true;
+          diag_tiles = 0;
+        }
         if (H <= 0 || jm1 < 0 || nops >= cap) {
           go = false;
           break;
