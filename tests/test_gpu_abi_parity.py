@@ -168,6 +168,74 @@ def test_concurrent_callers(oracle):
         assert (g.query, g.target, g.score, g.max_x, g.max_y) == (e["q"], e["t"], e["score"], e["max_x"], e["max_y"])
 
 
+def test_concurrent_packages_searches_and_single_calls(oracle):
+    """Everything at once from several threads: two work packages big enough for the two-in-flight driver, database
+    searches, and one-pair calls.  The library serialises submissions per device and shares pools (workspaces, ops
+    arenas, slabs); every caller must still get exactly what it gets alone."""
+    import ctypes as C
+    import threading
+    import dlsa_amd
+    from dlsa_amd import bridge
+    L = bridge.lib()
+    rng = random.Random(77)
+    s = dlsa_amd.AlignmentScore(2, -1, -1)
+    n = 36000
+    packs = []
+    for p in range(2):
+        qs = [_rnd(rng, 30 + 10 * p).encode() for _ in range(5)]
+        ts = [_rnd(rng, rng.randint(20, 70)).encode() for _ in range(n)]
+        packs.append((qs, ts))
+    targets = [_rnd(rng, rng.randint(50, 400)) for _ in range(600)]
+    db = bridge.Database(seqs=targets)
+    dq = _rnd(rng, 120)
+    singles = [(_rnd(rng, rng.randint(5, 90)), _rnd(rng, rng.randint(5, 200))) for _ in range(40)]
+
+    def run_pack(p):
+        qs, ts = packs[p]
+        qarr = (C.c_char_p * n)(*[qs[i % 5] for i in range(n)])
+        tarr = (C.c_char_p * n)(*ts)
+        out = (C.POINTER(bridge.CResult) * n)()
+        assert L.sw_align_batch(qarr, tarr, n, s.c(), 0, out) == 0
+        got = [(C.string_at(out[i].contents.query_ptr), C.string_at(out[i].contents.target_ptr), out[i].contents.score,
+                out[i].contents.max_x, out[i].contents.max_y) for i in range(0, n, 53)]
+        L.sw_free_alignment_results(out, n)
+        return got
+
+    def run_search():
+        return [[(h["target_index"], h["score"], h["query_aln"], h["target_aln"]) for h in db.search_topk(dq, s, 7)] for _ in range(6)]
+
+    def run_singles():
+        return [_gpu("lowmem", q, t, (-1, 2, -1)) for q, t in singles]
+
+    try:
+        alone = [run_pack(0), run_pack(1), run_search(), run_singles()]
+        res = [None] * 4
+        jobs = [lambda: run_pack(0), lambda: run_pack(1), run_search, run_singles]
+        errs = []
+
+        def work(k):
+            try:
+                res[k] = jobs[k]()
+            except BaseException as e:  # noqa: BLE001 -- reported below, in the main thread
+                errs.append((k, repr(e)))
+        th = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not errs, errs
+        assert res[0] == alone[0] and res[1] == alone[1] and res[2] == alone[2]
+        for a, b in zip(res[3], alone[3]):
+            assert (a.query, a.target, a.score, a.max_x, a.max_y) == (b.query, b.target, b.score, b.max_x, b.max_y)
+        # ... and what they get alone is the oracle's (sampled)
+        qs, ts = packs[0]
+        for k, i in enumerate(range(0, n, 53)):
+            if k % 40:
+                continue
+            e = oracle.align("lowmem", qs[i % 5].decode(), ts[i].decode(), -1, 2, -1)
+            assert (alone[0][k][0].decode(), alone[0][k][1].decode(), alone[0][k][2]) == (e["q"], e["t"], e["score"] & 0xFFFF)
+    finally:
+        db.close()
+
+
 def test_batch_results_freed_in_any_mix(oracle):
     """The results of one sw_align_batch call share a slab: every way of freeing them -- one by one, strings first, in
     bulk (sw_free_alignment_results), or a mix -- releases each exactly once; a later batch of the same shape (which
