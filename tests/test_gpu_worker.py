@@ -113,3 +113,47 @@ def test_fasta_to_result_files(oracle, tmp_path):
         want = "".join(f">{names[i]}\nAlignment: {exp[i]['q']}\nLength: {len(exp[i]['q'])}\nScore: {exp[i]['score']}\n\n"
                        for i in order)
         assert (out / f"{qname}.txt").read_text() == want
+
+
+def test_command_line_drivers(oracle, tmp_path, capsys):
+    """`python -m dlsa_amd work / search / benchmark`: a CompleteWorkPackage file in, the bodies the worker would POST
+    out (one JSON per line, 101 + 100 + ... results like worker_impl.go:158-166); the CLI's flags without the server."""
+    from dlsa_amd import __main__ as cli
+    rng = random.Random(52)
+    work = _package(rng, 3, 60)
+    pkg = {"id": work.id, "job_id": work.job_id, "match_score": work.match_score, "mismatch_penalty": work.mismatch_penalty,
+           "gap_penalty": work.gap_penalty, "sequences": work.sequences,
+           "queries": [{"query": c.query, "target": c.target} for c in work.queries]}
+    pf, of = tmp_path / "package.json", tmp_path / "posts.jsonl"
+    pf.write_text(json.dumps(pkg))
+    assert cli.main(["work", str(pf), "--out", str(of), "--cpus", "1"]) == 0
+    posts = [json.loads(line) for line in of.read_text().splitlines()]
+    assert [len(p["alignments"]) for p in posts] == [101, 79]
+    details = [d for p in posts for d in p["alignments"]]
+    for comb, d in zip(work.queries, details):
+        e = _expected(oracle, work, comb)
+        assert d["combination"] == {"target": comb.target, "query": comb.query}
+        a = d["alignment"]
+        assert (a["query_alignment"], a["target_alignment"], a["score"]) == (e["q"], e["t"], e["score"] & 0xFFFF)
+        assert (a["maxX"], a["maxY"]) == (_go_int(e["max_x"]), _go_int(e["max_y"]))
+    # the same package over a node handle (all GPUs of the box)
+    of2 = tmp_path / "posts_node.jsonl"
+    assert cli.main(["work", str(pf), "--out", str(of2), "--cpus", "1", "--node"]) == 0
+    assert of2.read_text() == of.read_text()
+    # search: the CLI's flags
+    qf, tf = tmp_path / "q.fasta", tmp_path / "db.fasta"
+    q = _rnd(rng, 90)
+    ts = {f"s{i}": _rnd(rng, rng.randint(40, 200)) for i in range(12)}
+    ts["s4"] = ts["s4"][:20] + q[10:80] + ts["s4"][20:]
+    qf.write_text(f">query1\n{q}\n")
+    tf.write_text("".join(f">{k}\n{v}\n" for k, v in ts.items()))
+    out = tmp_path / "res"
+    assert cli.main(["search", "--query", str(qf), "--database", str(tf), "--top-k", "2", "--output-path", str(out)]) == 0
+    text = (out / "query1.txt").read_text()
+    e = oracle.align("lowmem", q, ts["s4"], -1, 2, -1)
+    assert text.startswith(f">s4\nAlignment: {e['q']}\nLength: {len(e['q'])}\nScore: {e['score']}\n\n") and text.count(">") == 2
+    # benchmark: the registration body, integer-valued
+    capsys.readouterr()
+    assert cli.main(["benchmark"]) == 0
+    body = json.loads(capsys.readouterr().out)
+    assert body["benchmark_result"] > 1e11 and body["benchmark_result"] == float(int(body["benchmark_result"]))
