@@ -216,7 +216,8 @@ int sw_node_last_stats(const sw_node_db *db, int shard, struct sw_kernel_stats *
  * suite check the library's dispatch (rust/src/algorithm/mod.rs:213 and the padded-length quirks) against
  * the oracle's clean model without a GPU. */
 int sw_hip_path_params(int path, uint64_t q_len, uint64_t t_len, uint32_t out[4]);
-/* Counters of the last sw_align_batch / sw_execute_work call that took the work-package fast path (long ACGT
+/* Counters of the CALLING THREAD's last sw_align_batch / sw_execute_work / sw_node_align_batch /
+ * sw_node_execute_work call (a node call adds up its devices) that took the work-package fast path (long ACGT
  * targets: score pass by the packed inter-task kernel over overlapping chunks of the targets, end cell and traceback
  * inside windows of at most 256 target columns): out[0] = pairs it answered, out[1] = score passes (queries),
  * out[2] = windows filled by the exact kernel, out[3] = rounds (1 + continuations to the left), out[4] = cells of
