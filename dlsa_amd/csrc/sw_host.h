@@ -73,6 +73,10 @@ struct ExactHost {
   std::vector<ExactPair, NoInitAlloc<ExactPair>> hp;
   std::vector<size_t, NoInitAlloc<size_t>> qoff, toff, dirw;
   std::vector<uint32_t> unit_pair, unit_order;
+  // sequence id -> index of its copy in the current submission; an entry counts only if its stamp is the current
+  // epoch, so nothing is cleared between submissions
+  std::vector<uint64_t> id_copy;  // (epoch << 32) | index
+  uint32_t epoch = 0;
   void trim();  // gives the memory back when a submission was unusually large
 };
 

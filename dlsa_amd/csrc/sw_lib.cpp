@@ -294,7 +294,12 @@ int exact_chunk_begin(Context& c, Workspace& ws, const PairSpec* specs, size_t b
   if (erc) return erc;
   // symbol pool: every distinct sequence once (a database search shares one query)
   std::unordered_map<const uint16_t*, size_t> seen;  // pointer -> index into copies
-  std::vector<size_t> copy_by_id;                    // id -> index into copies
+  std::vector<uint64_t>& id_copy = ws.xh.id_copy;    // id -> (epoch, index into copies), kept between submissions
+  if (++ws.xh.epoch == 0) {                          // (wrapped: every stamp is stale and could look current)
+    std::fill(id_copy.begin(), id_copy.end(), 0);
+    ws.xh.epoch = 1;
+  }
+  const uint64_t epoch_tag = (uint64_t)ws.xh.epoch << 32;
   struct SeqCopy {
     const uint16_t* p;
     uint32_t len;
@@ -306,9 +311,12 @@ int exact_chunk_begin(Context& c, Workspace& ws, const PairSpec* specs, size_t b
   // different stretches of one target)
   auto add_seq = [&](const uint16_t* p, uint32_t len, uint32_t id) -> size_t {
     if (id != UINT32_MAX) {
-      if (id >= copy_by_id.size()) copy_by_id.resize((size_t)id + 1 + copy_by_id.size() / 2, SIZE_MAX);
-      if (copy_by_id[id] != SIZE_MAX && copies[copy_by_id[id]].len == len && copies[copy_by_id[id]].p == p)
-        return copies[copy_by_id[id]].off;
+      if (id >= id_copy.size()) id_copy.resize((size_t)id + 1 + id_copy.size() / 2, 0);
+      const uint64_t e = id_copy[id];
+      if ((e >> 32) == ws.xh.epoch) {
+        const SeqCopy& sc_ = copies[(uint32_t)e];
+        if (sc_.len == len && sc_.p == p) return sc_.off;
+      }
     } else {
       auto it = seen.find(p);
       if (it != seen.end() && copies[it->second].len == len) return copies[it->second].off;
@@ -316,7 +324,7 @@ int exact_chunk_begin(Context& c, Workspace& ws, const PairSpec* specs, size_t b
     const size_t off = pool_syms;
     copies.push_back(SeqCopy{p, len, off});
     pool_syms += (len + 1u) & ~(size_t)1;
-    if (id != UINT32_MAX) copy_by_id[id] = copies.size() - 1;
+    if (id != UINT32_MAX) id_copy[id] = epoch_tag | (uint64_t)(copies.size() - 1);
     else seen[p] = copies.size() - 1;
     return off;
   };
@@ -685,6 +693,7 @@ void swhip::ExactHost::trim() {
   decltype(dirw)().swap(dirw);
   std::vector<uint32_t>().swap(unit_pair);
   std::vector<uint32_t>().swap(unit_order);
+  std::vector<uint64_t>().swap(id_copy);
 }
 swhip::ArenaLease::ArenaLease() {
   std::lock_guard<std::mutex> lk(g_arena_mu);
@@ -911,34 +920,98 @@ bool swhip::ring_div_by_zero(int path, uint32_t Q, uint32_t T, Scoring sc) {
 
 
 // ---- host threads ---------------------------------------------------------------------------------------------
+// ---- host threads ---------------------------------------------------------------------------------------------
+// A work package calls parallel_ranges a dozen times (decode, tables, staging, strings, frees); creating 15 threads
+// each time cost more than some of the loops.  The helpers are therefore a pool, started on first use and kept for
+// the life of the process (never joined: they sleep on a condition variable).  Several callers may be in here at
+// once (the two host threads of a pipelined package, the shards of a node); a caller runs tasks itself -- its own
+// or anybody's -- until its job is done, so it never depends on a helper being there (e.g. in a forked child).
+namespace {
+struct PoolJob {
+  void (*fn)(void*, size_t, size_t);
+  void* arg;
+  std::atomic<size_t> remaining{0};
+  std::atomic<bool> failed{false};
+};
+struct PoolTask {
+  PoolJob* job;
+  size_t lo, hi;
+};
+struct Pool {
+  std::mutex mu;
+  std::condition_variable work_cv, done_cv;
+  std::vector<PoolTask> tasks;  // (a stack: order does not matter)
+  unsigned helpers = 0;
+};
+Pool& pool() {
+  static Pool* p = new Pool();  // never destroyed: helpers may be asleep in it at exit
+  return *p;
+}
+void pool_run(PoolTask t) noexcept {
+  try {
+    t.job->fn(t.job->arg, t.lo, t.hi);
+  } catch (...) {  // an exception inside a helper would end the process: flagged, re-raised by the job's owner
+    t.job->failed.store(true);
+  }
+  if (t.job->remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+    std::lock_guard<std::mutex> lk(pool().mu);  // (the owner checks `remaining` under the lock before it sleeps)
+    pool().done_cv.notify_all();
+  }
+}
+void pool_helper() noexcept {
+  Pool& P = pool();
+  std::unique_lock<std::mutex> lk(P.mu);
+  for (;;) {
+    P.work_cv.wait(lk, [&] { return !P.tasks.empty(); });
+    const PoolTask t = P.tasks.back();
+    P.tasks.pop_back();
+    lk.unlock();
+    pool_run(t);
+    lk.lock();
+  }
+}
+}  // namespace
+
 void swhip::parallel_ranges_impl(size_t n, unsigned nt, void (*fn)(void*, size_t, size_t), void* arg) {
   nt = std::min<unsigned>(nt, std::max(1u, std::thread::hardware_concurrency()));
   if (n < 2 * (size_t)nt) nt = 1;
-  // an exception inside a helper thread would end the process: it is caught there and re-raised by the caller
-  std::atomic<bool> failed{false};
-  auto run = [&](size_t lo, size_t hi) noexcept {
-    try {
-      fn(arg, lo, hi);
-    } catch (...) {
-      failed.store(true);
-    }
-  };
-  std::vector<std::thread> th;
-  th.reserve(nt);
-  for (unsigned t = 0; t < nt; t++) {
-    const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
-    if (t + 1 == nt) {
-      run(lo, hi);
-    } else {
+  if (nt <= 1) {
+    fn(arg, 0, n);
+    return;
+  }
+  Pool& P = pool();
+  PoolJob job;
+  job.fn = fn;
+  job.arg = arg;
+  job.remaining.store(nt);
+  {
+    std::unique_lock<std::mutex> lk(P.mu);
+    while (P.helpers + 1 < nt) {  // grow the pool to what this call wants (at most 15 helpers)
       try {
-        th.emplace_back(run, lo, hi);
-      } catch (...) {  // no thread to be had: do the range here
-        run(lo, hi);
+        std::thread(pool_helper).detach();
+      } catch (...) {
+        break;  // no thread to be had: the caller does the work
       }
+      P.helpers++;
+    }
+    for (unsigned t = 1; t < nt; t++) P.tasks.push_back(PoolTask{&job, n * t / nt, n * (t + 1) / nt});
+  }
+  P.work_cv.notify_all();
+  pool_run(PoolTask{&job, 0, n / nt});
+  std::unique_lock<std::mutex> lk(P.mu);
+  while (job.remaining.load(std::memory_order_acquire) != 0) {
+    if (!P.tasks.empty()) {  // help: mine or somebody else's
+      const PoolTask t = P.tasks.back();
+      P.tasks.pop_back();
+      lk.unlock();
+      pool_run(t);
+      lk.lock();
+    } else {
+      P.done_cv.wait(lk);
     }
   }
-  for (auto& x : th) x.join();
-  if (failed.load()) throw std::bad_alloc();
+  lk.unlock();
+  if (job.failed.load()) throw std::bad_alloc();
 }
 
 int swhip::align_many_on(int device, const char* const* queries, const char* const* targets, size_t n,
@@ -1105,9 +1178,20 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
   // A whole work package of short pairs: cut into a few sub-batches so that the result strings of one are assembled
   // (here) while the next is on the GPU (a second host thread drives it).  One slab per sub-batch.
   size_t scratch_est = 0;  // generous bound of the device scratch the pairs need together (direction bits dominate)
-  for (const PairSpec& sp : specs) scratch_est += (size_t)sp.Q * sp.T / 3 + 16 * ((size_t)sp.Q + sp.T) + 4096;
-  if (n_handled == 0 && specs.size() >= 32768 && scratch_est <= ((size_t)3 << 30)) {
-    const size_t B = std::min<size_t>(8, std::max<size_t>(2, specs.size() / 25000));
+  uint64_t cells_est = 0;
+  for (const PairSpec& sp : specs) {
+    scratch_est += (size_t)sp.Q * sp.T / 3 + 16 * ((size_t)sp.Q + sp.T) + 4096;
+    cells_est += (uint64_t)sp.Q * sp.T;
+  }
+  // (many pairs, or a few thousand with milliseconds of GPU work: below that one submission is quicker)
+  static const size_t pipe_min_pairs = [] {
+    const char* e = getenv("SW_HIP_PIPE_MIN_PAIRS");
+    return e ? (size_t)std::max(2, atoi(e)) : (size_t)2048;
+  }();
+  const bool worth = specs.size() >= 32768 || (specs.size() >= pipe_min_pairs && cells_est >= 2000000000ull);
+  if (n_handled == 0 && worth && scratch_est <= ((size_t)3 << 30)) {
+    size_t B = std::min<size_t>(8, std::max<size_t>(2, std::max<size_t>(specs.size() / 25000, (size_t)(cells_est / 4000000000ull))));
+    if (const char* e = getenv("SW_HIP_PIPE_PARTS")) B = std::min<size_t>(16, std::max(2, atoi(e)));  // experiments
     struct Part {
       ArenaLease lease;
       int rc = SW_OK;
