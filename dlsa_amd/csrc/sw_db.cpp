@@ -936,11 +936,15 @@ int swhip::db_score_persist_locked(Context& c, Workspace& ws, sw_db* db, const Q
   StreamDrain drain(c.stream);
   int rc = score_pass_locked(c, ws, db, qp.qwords.data(), qp.qwords.size(), Q, sc, nullptr, true);
   if (rc) return rc;
-  out.slot.resize(db->slot_target.size());
-  out.strip_best.resize((size_t)db->n_elems * 64);
+  const size_t slot_bytes = (db->slot_target.size() * 4 + 255) & ~(size_t)255, strip_bytes = (size_t)db->n_elems * 256;
+  out.host.a.resize(slot_bytes + strip_bytes + 256);
+  int32_t* const h_slot = (int32_t*)out.host.a.data();
+  uint32_t* const h_strip = (uint32_t*)(out.host.a.data() + slot_bytes);
+  out.slot = h_slot;
+  out.strip_best = h_strip;
   uint32_t kerr = 0;
-  HIPCK(hipMemcpyAsync(out.slot.data(), ws.slot_scores.p, out.slot.size() * 4, hipMemcpyDeviceToHost, c.stream));
-  HIPCK(hipMemcpyAsync(out.strip_best.data(), ws.strip_best.p, out.strip_best.size() * 4, hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipMemcpyAsync(h_slot, ws.slot_scores.p, db->slot_target.size() * 4, hipMemcpyDeviceToHost, c.stream));
+  if (strip_bytes) HIPCK(hipMemcpyAsync(h_strip, ws.strip_best.p, strip_bytes, hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipMemcpyAsync(&kerr, (uint32_t*)ws.ticket.p + 32, 4, hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipStreamSynchronize(c.stream));
   if ((rc = score_pass_finish_locked(c, db, Q, kerr))) return rc;
@@ -1043,6 +1047,13 @@ sw_db* swhip::db_create_on(Context* ctx, const char* flat, const uint64_t* offse
   return db_build(L.c, std::move(f), std::move(off));
 }
 // ... from sequences already gathered by the caller (the node sharder): takes ownership, no second copy
+// Takes the host copy of the sequences out of a database that is about to be freed (the temporary databases of the
+// work-package fast path hand their buffer on to the next one).
+std::string swhip::db_take_flat(sw_db* db) {
+  std::string out;
+  if (db) out.swap(db->flat);
+  return out;
+}
 sw_db* swhip::db_create_owned(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
   CtxLock L(ctx);
   if (L.rc) return nullptr;

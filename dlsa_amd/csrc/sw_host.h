@@ -365,8 +365,11 @@ Context* db_context(sw_db* db);
 // A score pass that leaves every inter-unit boundary column resident (ring slot = ticket) and reports, per strip
 // of the stream, the packed maxima of that strip alone.  Pointers stay valid until the next pass on the context.
 struct PersistPass {
-  std::vector<int32_t> slot;            // per slot: best score (32767 = saturated)
-  std::vector<uint32_t> strip_best;     // per strip 64 dwords (lo half: slot lane, hi half: slot 64 + lane)
+  // Host copies of the pass's two outputs, in a page-locked arena leased from the pool (14 MB per pass on the
+  // reference's synthetic data: pageable and freshly allocated they cost a millisecond per query).
+  ArenaLease host;
+  const int32_t* slot = nullptr;         // per slot: best score (32767 = saturated)
+  const uint32_t* strip_best = nullptr;  // per strip 64 dwords (lo half: slot lane, hi half: slot 64 + lane)
   const std::vector<ScoreUnit>* units = nullptr;   // ticket order
   const std::vector<ScoreGroup>* groups = nullptr;
   const std::vector<uint32_t>* slot_target = nullptr;
@@ -378,6 +381,7 @@ int db_score_persist_locked(Context& c, Workspace& ws, sw_db* db, const QueryPre
 size_t db_persist_ring_bytes(const sw_db* db, uint32_t Q, int cus);
 sw_db* db_create_on(Context* ctx, const char* flat, const uint64_t* offsets, uint64_t n);
 sw_db* db_create_owned(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off);
+std::string db_take_flat(sw_db* db);
 sw_db* db_open_on(Context* ctx, const char* path);  // a file written by sw_db_save
 const std::string& db_flat(const sw_db* db);
 const std::vector<uint64_t>& db_offsets(const sw_db* db);

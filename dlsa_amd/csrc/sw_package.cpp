@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <numeric>
 
@@ -38,10 +39,31 @@ bool acgt_only(const Decoded& d) {
   return true;
 }
 
+// The byte buffer of a temporary database (the chunks back to back, > 100 MB for a package of long targets) is
+// handed from one package to the next: a fresh std::string of that size is zero-filled and page-faulted in, which
+// cost as much as two score passes.  One buffer of at most 1 GB is kept.
+std::mutex g_flat_mu;
+std::string g_flat_cache;
+std::string flat_cache_take() {
+  std::lock_guard<std::mutex> lk(g_flat_mu);
+  std::string out;
+  out.swap(g_flat_cache);
+  return out;
+}
+void flat_cache_put(std::string&& s) {
+  if (s.capacity() == 0 || s.capacity() > ((size_t)1 << 30)) return;
+  std::lock_guard<std::mutex> lk(g_flat_mu);
+  if (s.capacity() > g_flat_cache.capacity()) g_flat_cache.swap(s);
+}
 struct DbHolder {
   sw_db* db = nullptr;
   ~DbHolder() {
-    if (db) sw_db_free(db);
+    if (!db) return;
+    try {
+      flat_cache_put(db_take_flat(db));
+    } catch (...) {
+    }
+    sw_db_free(db);
   }
 };
 
@@ -131,24 +153,25 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
       }
     }
     first_chunk[tids.size()] = (uint32_t)chunks.size();
-    std::string flat;
+    std::string flat = flat_cache_take();  // (resize below keeps what it has: no fill, pages already mapped)
     std::vector<uint64_t> off(chunks.size() + 1, 0);
     size_t total = 0;
     for (const Chunk& c : chunks) total += c.len;
-    flat.resize(total);
-    size_t at = 0;
-    for (size_t i = 0; i < chunks.size(); i++) {
-      memcpy(&flat[at], dec[chunks[i].tid].src + chunks[i].start, chunks[i].len);  // (ASCII: one byte per symbol)
-      at += chunks[i].len;
-      off[i + 1] = at;
-    }
     StageTimer tm(100000);
+    flat.resize(total);
+    for (size_t i = 0; i < chunks.size(); i++) off[i + 1] = off[i] + chunks[i].len;
+    parallel_ranges(chunks.size(), total, [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; i++)  // (ASCII: one byte per symbol)
+        memcpy(&flat[off[i]], dec[chunks[i].tid].src + chunks[i].start, chunks[i].len);
+    });
+    tm.lap("  windows: chunks");
     DbHolder holder;
     holder.db = db_create_owned(ctx, std::move(flat), std::move(off));
     tm.lap("  windows: temp db");
     if (!holder.db) return SW_E_HIP;
     sw_db* db = holder.db;
     st.chunks += chunks.size();
+    PersistPass pp;  // (its host buffers serve every query of the set)
     for (uint32_t qid : set.second) {
       const Decoded& q = dec[qid];
       const uint32_t Q = (uint32_t)q.sym.size();
@@ -165,7 +188,6 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
       CtxLock L(ctx);  // the boundary ring must stay as the score pass left it until this query's windows are done
       if (L.rc) return L.rc;
       if (db_persist_ring_bytes(db, Q, L.c->cus) > 2 * L.c->scratch_budget) continue;  // whole-matrix path instead
-      PersistPass pp;
       if ((rc = db_score_persist_locked(*L.c, L.c->ws, db, qp, sc, pp))) return rc;
       st.queries++;
       if (tm.on) fprintf(stderr, "[sw_hip]   windows: score kernel %.3f ms (Q = %u)\n", L.c->stats.score_kernel_ms, Q);
