@@ -201,6 +201,7 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
       for (size_t sl = 0; sl < pp.slot_target->size(); sl++)
         if ((*pp.slot_target)[sl] != UINT32_MAX) slot_of[(*pp.slot_target)[sl]] = (uint32_t)sl;
       // ---- round 1: the windows that can hold the end cell
+      constexpr uint32_t kNearStrips = 4;
       struct Win {
         size_t pair;     // index into `pairs`
         uint32_t chunk;  // database sequence
@@ -239,11 +240,17 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
             const uint32_t e = G.strip_base + st_;
             if ((int32_t)(int16_t)((pp.strip_best[(size_t)e * 64 + lane] >> shift) & 0xffffu) != s) continue;
             const uint32_t u = unit_of_elem[e];
-            const uint32_t first = std::max(units[u].first_elem, G.strip_base);
+            uint32_t entry = u;  // the unit at whose left boundary the window is entered
+            // a maximum within a few strips of its unit's left boundary: the alignment very likely crosses it, and a
+            // continuation round costs a whole submission -- enter one unit earlier right away
+            if (e - std::max(units[u].first_elem, G.strip_base) < kNearStrips && units[u].first_elem > G.strip_base &&
+                units[u].dep != UINT32_MAX)
+              entry = units[u].dep;
+            const uint32_t first = std::max(units[entry].first_elem, G.strip_base);
             const uint32_t col0 = (first - G.strip_base) * kScoreR;
             const uint32_t cols = std::min(C.len, (st_ + 1) * kScoreR) - col0;
-            if (u == last_unit) wins.back().cols = cols;  // a later strip of the same unit: widen
-            else wins.push_back(Win{pi, c, u, col0, cols});
+            if (u == last_unit) wins.back().cols = C.len < (st_ + 1) * kScoreR ? C.len - wins.back().col0 : (st_ + 1) * kScoreR - wins.back().col0;  // a later strip of the same unit: widen
+            else wins.push_back(Win{pi, c, entry, col0, cols});
             last_unit = u;
           }
         }
@@ -333,8 +340,12 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
             // next window spans 2, 4, 8, ... units (every unit boundary has its column stored, so any unit can be
             // the entry): a long alignment costs a logarithmic number of rounds, a short one few cells.
             const ScoreGroup& G = groups[slot_of[wins[w].chunk] / kGroupTargets];
+            // ... and never fewer than the rows still above the resume point suggest: with the usual scorings a
+            // path that has left its first window runs on diagonally to the top of the matrix (x rows left ~ 1.5 x
+            // columns at most), so the second submission is normally the last.
             uint32_t up = units[wins[w].unit].dep;
-            for (uint32_t more = (1u << std::min<uint32_t>(round_no + 1, 4)) - 1;
+            const uint32_t by_rows = (o.end_x + o.end_x / 2) / (kScoreR * 16) + 1;
+            for (uint32_t more = std::max<uint32_t>((1u << std::min<uint32_t>(round_no + 1, 4)) - 1, std::min<uint32_t>(by_rows, 64));
                  more > 0 && units[up].first_elem > G.strip_base && units[up].dep != UINT32_MAX; more--)
               up = units[up].dep;
             const uint32_t first = std::max(units[up].first_elem, G.strip_base);
@@ -347,6 +358,7 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
             T_.done = true;
           }
         }
+        if (tm.on) fprintf(stderr, "[sw_hip]   windows: round %u: %zu windows, %zu continue\n", round_no, wins.size(), next.size());
         wins.swap(next);
         first_round = false;
         round_no++;
