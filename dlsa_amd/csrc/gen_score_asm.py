@@ -2,14 +2,22 @@
 """Generates dlsa_amd/csrc/sw_score_asm.inc: the hand-scheduled gfx950 row loop of the inter-task score
 kernel (sw_score.hip) as one inline-asm string.
 
-Why generated asm: the loop body exists in 8 variants (4 query nucleotides x 2 row parities) that must all
-update the 16 H registers IN PLACE and read 64 table registers; hipcc's register allocator inserted 16-32
-register copies per row around any C++ / per-cell inline-asm formulation (see DESIGN.md "Score kernel").
-Here every register is named explicitly:
+Why generated asm: the loop body must update the 16 H registers IN PLACE and read one of four tables of 16
+registers, chosen by the row's query nucleotide; hipcc's register allocator inserted 16-32 register copies per
+row around any C++ / per-cell inline-asm formulation (see DESIGN.md "Score kernel").  Here every register is named
+explicitly:
 
   v48..v63    H[0..15]            (pinned in/out operands of the asm statement, 4 tuples of 4)
-  v64..v79    tabA[0..15]   v80..v95 tabC   v96..v111 tabG   v112..v127 tabT   (pinned inputs)
+  v64..v127   tab[column][nucleotide]: v(64 + 4 r + c) = score of column r against nucleotide c (A, C, G, T)
+              (pinned inputs, one tuple of 4 per column)
   v40 m  v41 n  v42 a  v43 d  v44 L1  v45 D1  v46 L0  v47 D0     (clobbered temporaries)
+
+The table is selected WITHOUT a branch: the loop runs in VGPR index mode (s_set_gpr_idx_on ... gpr_idx(SRC2)), the
+row's nucleotide code goes into the index with one s_set_gpr_idx_idx, and diag + s is a v_pk_mad_i16 h * 1 + tab
+whose third source names the A column register -- the hardware adds the index, so the same instruction reads the
+A, C, G or T entry.  Only that instruction has a third source, so nothing else is affected.  (The first version had
+four copies of the body behind a 4-way scalar branch: 2 % slower on the bench shape, 4 x the code.)  M0 holds the
+index and is saved / restored around the loop (the compiler keeps the LDS-DMA base in it).
 
 Per cell (see sw_score.hip for the recurrence): v_pk_max_i16, v_pk_sub_u16 clamp, v_pk_add_i16 clamp (the
 NEXT cell's diag + s, computed before the old H is overwritten), v_pk_max_i16, and on odd columns the running
@@ -32,36 +40,41 @@ def h(r):
     return f"v{H0 + r}"
 
 
-def tab(code, r):
-    return f"v{TAB0 + 16 * code + r}"
+def tab(r):
+    """the A entry of column r; index mode adds the row's nucleotide code (0..3)"""
+    return f"v{TAB0 + 4 * r}"
 
 
-def cells4(code, r0, hl):
+def mad(dst, hsrc, r):
+    """dst = sat(hsrc + tab[r][nucleotide of this row]) for both packed halves"""
+    return f"v_pk_mad_i16 {dst}, {hsrc}, %[one], {tab(r)} clamp"
+
+
+def cells4(r0, hl):
     """four cells r0..r0+3; d (v43) holds diag+s of cell r0 on entry and of cell r0+4 on exit"""
-    t = lambda r: tab(code, min(r, 15))
     h0, h1, h2, h3 = h(r0), h(r0 + 1), h(r0 + 2), h(r0 + 3)
     m, n, a, d = f"v{M}", f"v{N}", f"v{A}", f"v{D}"
     return [
         f"v_pk_max_i16 {m}, {hl}, {h0}",
-        f"v_pk_add_i16 {a}, {h0}, {t(r0 + 1)} clamp",
+        mad(a, h0, r0 + 1),
         f"v_pk_sub_u16 {m}, {m}, %[g] clamp",
         "s_nop 0",
         f"v_pk_max_i16 {h0}, {m}, {d}",
         "s_nop 0",
         f"v_pk_max_i16 {m}, {h0}, {h1}",
-        f"v_pk_add_i16 {d}, {h1}, {t(r0 + 2)} clamp",
+        mad(d, h1, r0 + 2),
         f"v_pk_sub_u16 {n}, {m}, %[g] clamp",
         f"v_pk_max_i16 %[best], %[best], {m}",
         f"v_pk_max_i16 {h1}, {n}, {a}",
         "s_nop 0",
         f"v_pk_max_i16 {m}, {h1}, {h2}",
-        f"v_pk_add_i16 {a}, {h2}, {t(r0 + 3)} clamp",
+        mad(a, h2, r0 + 3),
         f"v_pk_sub_u16 {m}, {m}, %[g] clamp",
         "s_nop 0",
         f"v_pk_max_i16 {h2}, {m}, {d}",
         "s_nop 0",
         f"v_pk_max_i16 {m}, {h2}, {h3}",
-    ] + ([f"v_pk_add_i16 {d}, {h3}, {t(r0 + 4)} clamp"] if r0 + 4 < 16 else ["s_nop 0"]) + [
+    ] + ([mad(d, h3, r0 + 4)] if r0 + 4 < 16 else ["s_nop 0"]) + [
         f"v_pk_sub_u16 {n}, {m}, %[g] clamp",
         f"v_pk_max_i16 %[best], %[best], {m}",
         f"v_pk_max_i16 {h3}, {n}, {a}",
@@ -69,12 +82,12 @@ def cells4(code, r0, hl):
     ]
 
 
-def body(code, parity):
+def body(parity):
     left, diag = (f"v{L0}", f"v{D0}") if parity == 0 else (f"v{L1}", f"v{D1}")
-    out = [f"v_pk_add_i16 v{D}, {diag}, {tab(code, 0)} clamp"]
-    out += cells4(code, 0, left)
+    out = [mad(f"v{D}", diag, 0)]
+    out += cells4(0, left)
     for r0 in (4, 8, 12):
-        out += cells4(code, r0, h(r0 - 1))
+        out += cells4(r0, h(r0 - 1))
     return out
 
 
@@ -89,13 +102,10 @@ def row(parity):
     o = [f"ds_read_b32 v{nl}, %[addr] offset:{off + 256}",   # next row's left
          f"ds_read_b32 v{nd}, %[addr] offset:{off}",         # this row's left = next row's diag
          "s_waitcnt lgkmcnt(3)",
-         "s_bitcmp1_b32 %[qw], 1", f"s_cbranch_scc1 Lhi_{p}_%=",
-         "s_bitcmp1_b32 %[qw], 0", f"s_cbranch_scc1 LC_{p}_%="]
-    o += body(0, parity) + [f"s_branch Ljoin_{p}_%=", f"LC_{p}_%=:"]
-    o += body(1, parity) + [f"s_branch Ljoin_{p}_%=", f"Lhi_{p}_%=:",
-                            "s_bitcmp1_b32 %[qw], 0", f"s_cbranch_scc1 LT_{p}_%="]
-    o += body(2, parity) + [f"s_branch Ljoin_{p}_%=", f"LT_{p}_%=:"]
-    o += body(3, parity) + [f"Ljoin_{p}_%=:", "s_lshr_b32 %[qw], %[qw], 2",
+         "s_and_b32 %[t], %[qw], 3",        # this row's nucleotide selects the table entry (index mode, SRC2)
+         "s_set_gpr_idx_idx %[t]",
+         "s_nop 0"]
+    o += body(parity) + ["s_lshr_b32 %[qw], %[qw], 2",
                             f"ds_write_b32 %[waddr], {h(15)} offset:{off}",
                             "s_bitcmp1_b32 %[n], 9", f"s_cbranch_scc0 Lng_{p}_%=",
                             f"global_store_dword %[goff], {h(15)}, %[gb] sc1",
@@ -104,9 +114,12 @@ def row(parity):
 
 
 def generate():
-    o = [f"v_mov_b32_e32 v{D0}, %[diag]",
+    o = ["s_mov_b32 %[m0s], m0",                       # the compiler's M0 (LDS-DMA base) comes back at the exit
+         f"v_mov_b32_e32 v{D0}, %[diag]",
          f"ds_read_b32 v{L0}, %[addr]",
          "s_and_b32 %[i], %[n], 0xff",
+         "s_mov_b32 %[t], 0",
+         "s_set_gpr_idx_on %[t], gpr_idx(SRC2)",       # from here to Lexit a VALU third source is v[n + index]
          "s_waitcnt lgkmcnt(0)",
          "Ltop_%=:"]
     o += row(0)
@@ -116,6 +129,8 @@ def generate():
           "v_add_u32_e32 %[waddr], 0x200, %[waddr]",
           "s_sub_u32 %[i], %[i], 1", "s_cmp_lg_u32 %[i], 0", "s_cbranch_scc1 Ltop_%=",
           "Lexit_%=:",
+          "s_set_gpr_idx_off",
+          "s_mov_b32 m0, %[m0s]",
           "s_waitcnt lgkmcnt(0)",   # the prefetches into L0/D0 have landed before the registers are released
           f"v_mov_b32_e32 %[diag], v{D0}"]
     return o
@@ -129,16 +144,16 @@ def counts():
     """Instruction counts of ONE query row of one strip (16 columns x 2 targets per lane), read off the generated
     text so that measurement code (sw_hip_last_stats, bench.py) never carries a hand-copied constant: packed VALU
     instructions of a row body, the other VALU instructions of the loop per row (address increments), s_nops."""
-    b = body(0, 0)
-    assert all(len(body(c, p)) == len(b) for c in range(4) for p in range(2))
+    b = body(0)
+    assert len(body(1)) == len(b)
     packed = sum(1 for ln in b if ln.startswith("v_pk_"))
     snop = sum(1 for ln in b if ln.startswith("s_nop"))
     loop = generate()
     top = loop.index("Ltop_%=:")
     two_rows = loop[top:loop.index("Lexit_%=:")]
     other = sum(1 for ln in two_rows if is_valu(ln) and not ln.startswith("v_pk_"))
-    # the loop text holds 4 bodies per row parity; `other` counts the per-2-row address increments plus one
-    # v_add per row parity that only executes when the row is also stored to global memory
+    # `other` counts the per-2-row address increments plus one v_add per row parity that only executes when the
+    # row is also stored to global memory
     aux_always = sum(1 for ln in two_rows if ln.startswith("v_add_u32_e32 %[addr]") or ln.startswith("v_add_u32_e32 %[waddr]"))
     aux_store = sum(1 for ln in two_rows if ln.startswith("v_add_u32_e32 %[goff]"))
     assert other == aux_always + aux_store and aux_always == 2 and aux_store == 2

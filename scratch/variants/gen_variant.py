@@ -38,7 +38,43 @@ def row(parity):
     return o
 
 
+if "gpridx" in flags:
+    # one body per row parity: the substitution table of the row's nucleotide is selected by VGPR index mode
+    # (s_set_gpr_idx, SRC2 relative) on a v_pk_mad_i16 h * 1 + tab instead of a 4-way branch to four bodies
+    import re
+    def cells4_idx(code, r0, hl):
+        out = []
+        for ln in orig_cells4(0, r0, hl):
+            m = re.match(r"v_pk_add_i16 (v\d+), (v\d+), (v\d+) clamp", ln)
+            out.append(f"v_pk_mad_i16 {m.group(1)}, {m.group(2)}, %[one], {m.group(3)} clamp" if m else ln)
+        return out
+    base.cells4 = cells4_idx
+    orig_body = base.body
+    def body_idx(code, parity):
+        out = []
+        for ln in orig_body(0, parity):
+            m = re.match(r"v_pk_add_i16 (v\d+), (v\d+), (v\d+) clamp", ln)
+            out.append(f"v_pk_mad_i16 {m.group(1)}, {m.group(2)}, %[one], {m.group(3)} clamp" if m else ln)
+        return out
+    base.body = body_idx
+    def row_idx(parity):
+        o = orig_row(parity)
+        p = "e" if parity == 0 else "o"
+        i0 = o.index("s_bitcmp1_b32 %[qw], 1")
+        i1 = o.index(f"Ljoin_{p}_%=:")
+        return o[:i0] + ["s_and_b32 %[t], %[qw], 3", "s_lshl_b32 %[t], %[t], 4", "s_set_gpr_idx_idx %[t]"] + base.body(0, parity) + o[i1:]
+    row = row_idx
+    _gen0 = base.generate
+    def generate_idx():
+        o = _gen0()
+        top = o.index("Ltop_%=:")
+        o[top:top] = ["s_mov_b32 %[t], 0", "s_set_gpr_idx_on %[t], gpr_idx(SRC2)"]
+        ex = o.index("Lexit_%=:")
+        o[ex + 1:ex + 1] = ["s_set_gpr_idx_off"]
+        return o
 base.row = row
+if "gpridx" in flags:
+    base.generate = generate_idx
 orig_generate = base.generate
 if "storeool" in flags:
     def generate():
