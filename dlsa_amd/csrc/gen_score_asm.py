@@ -91,8 +91,7 @@ def body(parity):
     return out
 
 
-def row(parity):
-    p = "e" if parity == 0 else "o"
+def row(parity, store):
     nl, nd = (L1, D1) if parity == 0 else (L0, D0)
     off = 256 * parity
     # LDS ops retire in order.  Outstanding here, oldest first: this row's two reads (issued one row ago), the
@@ -106,14 +105,17 @@ def row(parity):
          "s_set_gpr_idx_idx %[t]",
          "s_nop 0"]
     o += body(parity) + ["s_lshr_b32 %[qw], %[qw], 2",
-                            f"ds_write_b32 %[waddr], {h(15)} offset:{off}",
-                            "s_bitcmp1_b32 %[n], 9", f"s_cbranch_scc0 Lng_{p}_%=",
-                            f"global_store_dword %[goff], {h(15)}, %[gb] sc1",
-                            "v_add_u32_e32 %[goff], 0x100, %[goff]", f"Lng_{p}_%=:"]
+                         f"ds_write_b32 %[waddr], {h(15)} offset:{off}"]
+    if store:  # the wave whose last column feeds the next unit (another workgroup) through HBM
+        o += [f"global_store_dword %[goff], {h(15)}, %[gb] sc1",
+              "v_add_u32_e32 %[goff], 0x100, %[goff]"]
     return o
 
 
-def generate():
+def generate(store=False):
+    """the loop in one of its two forms: without / with the store of the wave's last column to global memory.
+    The kernel picks the form per block outside the loop (one wave in 16 stores, and only in chained units); a
+    test inside the loop cost every wave a scalar compare and a taken branch per row."""
     o = ["s_mov_b32 %[m0s], m0",                       # the compiler's M0 (LDS-DMA base) comes back at the exit
          f"v_mov_b32_e32 v{D0}, %[diag]",
          f"ds_read_b32 v{L0}, %[addr]",
@@ -122,9 +124,9 @@ def generate():
          "s_set_gpr_idx_on %[t], gpr_idx(SRC2)",       # from here to Lexit a VALU third source is v[n + index]
          "s_waitcnt lgkmcnt(0)",
          "Ltop_%=:"]
-    o += row(0)
+    o += row(0, store)
     o += ["s_sub_u32 %[i], %[i], 1", "s_cmp_eq_u32 %[i], 0", "s_cbranch_scc1 Lexit_%="]
-    o += row(1)
+    o += row(1, store)
     o += ["v_add_u32_e32 %[addr], 0x200, %[addr]",
           "v_add_u32_e32 %[waddr], 0x200, %[waddr]",
           "s_sub_u32 %[i], %[i], 1", "s_cmp_lg_u32 %[i], 0", "s_cbranch_scc1 Ltop_%=",
@@ -148,7 +150,7 @@ def counts():
     assert len(body(1)) == len(b)
     packed = sum(1 for ln in b if ln.startswith("v_pk_"))
     snop = sum(1 for ln in b if ln.startswith("s_nop"))
-    loop = generate()
+    loop = generate(True)
     top = loop.index("Ltop_%=:")
     two_rows = loop[top:loop.index("Lexit_%=:")]
     other = sum(1 for ln in two_rows if is_valu(ln) and not ln.startswith("v_pk_"))
@@ -163,7 +165,6 @@ def counts():
 def render(Dslots=3, B=12):
     """the text of sw_score_asm.inc (ring geometry must match sw_score.hip: D slots x B rows x 256 bytes per wave;
     the asm text itself does not depend on them; B must be even)"""
-    lines = generate()
     c = counts()
     out = ["// GENERATED by gen_score_asm.py -- do not edit.  Row loop of sw_score_kernel (gfx950).\n",
            f"#define SW_SCORE_ASM_D {Dslots}\n#define SW_SCORE_ASM_B {B}\n",
@@ -172,11 +173,16 @@ def render(Dslots=3, B=12):
            f"#define SW_SCORE_ASM_AUX_PER_2ROWS {c['aux_x2']}    /* address increments, once per two rows */\n",
            f"#define SW_SCORE_ASM_STORE_PER_ROW {c['store']}    /* extra VALU of a row that is also stored to HBM */\n",
            f"#define SW_SCORE_ASM_SNOP_PER_ROW {c['snop']}\n",
-           "#define SW_SCORE_ROWS_ASM \\\n"]
-    for ln in lines:
-        out.append(f'  "{ln}\\n\\t" \\\n')
-    out.append('  ""\n')
-    return "".join(out), len(lines)
+           ]
+    n = 0
+    for name, store in (("SW_SCORE_ROWS_ASM", False), ("SW_SCORE_ROWS_STORE_ASM", True)):
+        lines = generate(store)
+        n += len(lines)
+        out.append(f"#define {name} \\\n")
+        for ln in lines:
+            out.append(f'  "{ln}\\n\\t" \\\n')
+        out.append('  ""\n')
+    return "".join(out), n
 
 
 def main():
