@@ -138,28 +138,58 @@ def generate(store=False):
     return o
 
 
+def generate_block(store, rows=12):
+    """a FULL block of `rows` query rows, unrolled: no loop counter, no taken branch, the row's nucleotide extracted
+    with one s_bfe, every LDS / global offset an immediate (the addresses move once per block, in the kernel).
+    Same registers and the same entry / exit contract as generate(); only blocks shorter than `rows` (the last one
+    of a query) go through the loop form."""
+    assert rows % 2 == 0 and 256 * (rows + 1) < 65536 and 256 * rows < 4096
+    o = ["s_mov_b32 %[m0s], m0",
+         f"v_mov_b32_e32 v{D0}, %[diag]",
+         f"ds_read_b32 v{L0}, %[addr]",
+         "s_mov_b32 %[t], 0",
+         "s_set_gpr_idx_on %[t], gpr_idx(SRC2)",
+         "s_waitcnt lgkmcnt(0)"]
+    for i in range(rows):
+        parity = i & 1
+        nl, nd = (L1, D1) if parity == 0 else (L0, D0)
+        o += [f"ds_read_b32 v{nl}, %[addr] offset:{256 * (i + 1)}",   # next row's left
+              f"ds_read_b32 v{nd}, %[addr] offset:{256 * i}",         # this row's left = next row's diag
+              "s_waitcnt lgkmcnt(3)",                                  # (see row(): two reads needed, three may fly)
+              f"s_bfe_u32 %[t], %[qw], {hex((2 << 16) | (2 * i))}",
+              "s_set_gpr_idx_idx %[t]",
+              "s_nop 0"]
+        o += body(parity)
+        o += [f"ds_write_b32 %[waddr], {h(15)} offset:{256 * i}"]
+        if store:
+            o += [f"global_store_dword %[goff], {h(15)}, %[gb] offset:{256 * i} sc1"]
+    if store:
+        o += [f"v_add_u32_e32 %[goff], {hex(256 * rows)}, %[goff]"]
+    o += ["s_set_gpr_idx_off",
+          "s_mov_b32 m0, %[m0s]",
+          "s_waitcnt lgkmcnt(0)",
+          f"v_mov_b32_e32 %[diag], v{D0}"]
+    return o
+
+
 def is_valu(ln):
     return ln.startswith("v_")
 
 
 def counts():
-    """Instruction counts of ONE query row of one strip (16 columns x 2 targets per lane), read off the generated
-    text so that measurement code (sw_hip_last_stats, bench.py) never carries a hand-copied constant: packed VALU
-    instructions of a row body, the other VALU instructions of the loop per row (address increments), s_nops."""
+    """Instruction counts of ONE query row of one strip (16 columns x 2 targets per lane) in the form that does the
+    work -- the unrolled full block -- read off the generated text so that measurement code (sw_hip_last_stats,
+    bench.py) never carries a hand-copied constant: packed VALU instructions of a row, other VALU instructions per
+    two rows and per stored row (none since the block is unrolled: the addresses are immediates; what is left is two
+    v_mov per BLOCK of 12 rows and one v_add per stored block, not counted), s_nops."""
     b = body(0)
     assert len(body(1)) == len(b)
     packed = sum(1 for ln in b if ln.startswith("v_pk_"))
     snop = sum(1 for ln in b if ln.startswith("s_nop"))
-    loop = generate(True)
-    top = loop.index("Ltop_%=:")
-    two_rows = loop[top:loop.index("Lexit_%=:")]
-    other = sum(1 for ln in two_rows if is_valu(ln) and not ln.startswith("v_pk_"))
-    # `other` counts the per-2-row address increments plus one v_add per row parity that only executes when the
-    # row is also stored to global memory
-    aux_always = sum(1 for ln in two_rows if ln.startswith("v_add_u32_e32 %[addr]") or ln.startswith("v_add_u32_e32 %[waddr]"))
-    aux_store = sum(1 for ln in two_rows if ln.startswith("v_add_u32_e32 %[goff]"))
-    assert other == aux_always + aux_store and aux_always == 2 and aux_store == 2
-    return {"packed": packed, "snop": snop, "aux_x2": aux_always, "store": aux_store // 2}
+    blk = generate_block(True)
+    other = sum(1 for ln in blk if is_valu(ln) and not ln.startswith("v_pk_"))
+    assert sum(1 for ln in blk if ln.startswith("v_pk_")) == 12 * packed and other == 3
+    return {"packed": packed, "snop": snop, "aux_x2": 0, "store": 0}
 
 
 def render(Dslots=3, B=12):
@@ -170,13 +200,14 @@ def render(Dslots=3, B=12):
            f"#define SW_SCORE_ASM_D {Dslots}\n#define SW_SCORE_ASM_B {B}\n",
            "// executed instructions per query row of one strip (wave-instructions; 16 columns x 128 targets):\n",
            f"#define SW_SCORE_ASM_PACKED_PER_ROW {c['packed']}   /* v_pk_* of one row body */\n",
-           f"#define SW_SCORE_ASM_AUX_PER_2ROWS {c['aux_x2']}    /* address increments, once per two rows */\n",
-           f"#define SW_SCORE_ASM_STORE_PER_ROW {c['store']}    /* extra VALU of a row that is also stored to HBM */\n",
+           f"#define SW_SCORE_ASM_AUX_PER_2ROWS {c['aux_x2']}    /* other VALU per two rows (none: unrolled block, immediate offsets) */\n",
+           f"#define SW_SCORE_ASM_STORE_PER_ROW {c['store']}    /* extra VALU of a row that is also stored to HBM (none; one per stored block) */\n",
            f"#define SW_SCORE_ASM_SNOP_PER_ROW {c['snop']}\n",
            ]
     n = 0
-    for name, store in (("SW_SCORE_ROWS_ASM", False), ("SW_SCORE_ROWS_STORE_ASM", True)):
-        lines = generate(store)
+    for name, store, full in (("SW_SCORE_ROWS_ASM", False, False), ("SW_SCORE_ROWS_STORE_ASM", True, False),
+                              ("SW_SCORE_BLOCK_ASM", False, True), ("SW_SCORE_BLOCK_STORE_ASM", True, True)):
+        lines = generate_block(store, B) if full else generate(store)
         n += len(lines)
         out.append(f"#define {name} \\\n")
         for ln in lines:
