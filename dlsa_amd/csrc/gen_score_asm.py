@@ -153,12 +153,13 @@ def generate_block(store, rows=12):
     for i in range(rows):
         parity = i & 1
         nl, nd = (L1, D1) if parity == 0 else (L0, D0)
-        o += [f"ds_read_b32 v{nl}, %[addr] offset:{256 * (i + 1)}",   # next row's left
-              f"ds_read_b32 v{nd}, %[addr] offset:{256 * i}",         # this row's left = next row's diag
-              "s_waitcnt lgkmcnt(3)",                                  # (see row(): two reads needed, three may fly)
-              f"s_bfe_u32 %[t], %[qw], {hex((2 << 16) | (2 * i))}",
+        # (the index moves first: the three LDS instructions keep it clear of the row's first indexed read, and the
+        # previous row's last indexed read lies 13 instructions back)
+        o += [f"s_bfe_u32 %[t], %[qw], {hex((2 << 16) | (2 * i))}",
               "s_set_gpr_idx_idx %[t]",
-              "s_nop 0"]
+              f"ds_read_b32 v{nl}, %[addr] offset:{256 * (i + 1)}",   # next row's left
+              f"ds_read_b32 v{nd}, %[addr] offset:{256 * i}",         # this row's left = next row's diag
+              "s_waitcnt lgkmcnt(3)"]                                  # (see row(): two reads needed, three may fly)
         o += body(parity)
         o += [f"ds_write_b32 %[waddr], {h(15)} offset:{256 * i}"]
         if store:
