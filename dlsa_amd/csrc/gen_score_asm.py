@@ -150,17 +150,26 @@ def generate_block(store, rows=12):
          "s_mov_b32 %[t], 0",
          "s_set_gpr_idx_on %[t], gpr_idx(SRC2)",
          "s_waitcnt lgkmcnt(0)"]
+    def index_of_row(i):
+        return [f"s_bfe_u32 %[t], %[qw], {hex((2 << 16) | (2 * i))}", "s_set_gpr_idx_idx %[t]"]
+
+    o += index_of_row(0)
     for i in range(rows):
         parity = i & 1
         nl, nd = (L1, D1) if parity == 0 else (L0, D0)
-        # (the index moves first: the three LDS instructions keep it clear of the row's first indexed read, and the
-        # previous row's last indexed read lies 13 instructions back)
-        o += [f"s_bfe_u32 %[t], %[qw], {hex((2 << 16) | (2 * i))}",
-              "s_set_gpr_idx_idx %[t]",
-              f"ds_read_b32 v{nl}, %[addr] offset:{256 * (i + 1)}",   # next row's left
+        o += [f"ds_read_b32 v{nl}, %[addr] offset:{256 * (i + 1)}",   # next row's left
               f"ds_read_b32 v{nd}, %[addr] offset:{256 * i}",         # this row's left = next row's diag
               "s_waitcnt lgkmcnt(3)"]                                  # (see row(): two reads needed, three may fly)
-        o += body(parity)
+        b = body(parity)
+        if i + 1 < rows:
+            # the NEXT row's index goes where this row's last two wait states were (both lie behind the row's last
+            # indexed read, and any instruction serves as a wait state): two issue slots less per row
+            last_mad = max(k for k, ln in enumerate(b) if ln.startswith("v_pk_mad_i16"))
+            nops = [k for k, ln in enumerate(b) if ln == "s_nop 0" and k > last_mad]
+            assert len(nops) >= 2
+            nxt = index_of_row(i + 1)
+            b[nops[-2]], b[nops[-1]] = nxt[0], nxt[1]
+        o += b
         o += [f"ds_write_b32 %[waddr], {h(15)} offset:{256 * i}"]
         if store:
             o += [f"global_store_dword %[goff], {h(15)}, %[gb] offset:{256 * i} sc1"]
