@@ -148,8 +148,7 @@ def generate_block(store, rows=12):
          f"v_mov_b32_e32 v{D0}, %[diag]",
          f"ds_read_b32 v{L0}, %[addr]",
          "s_mov_b32 %[t], 0",
-         "s_set_gpr_idx_on %[t], gpr_idx(SRC2)",
-         "s_waitcnt lgkmcnt(0)"]
+         "s_set_gpr_idx_on %[t], gpr_idx(SRC2)"]
     def index_of_row(i):
         return [f"s_bfe_u32 %[t], %[qw], {hex((2 << 16) | (2 * i))}", "s_set_gpr_idx_idx %[t]"]
 
@@ -157,10 +156,15 @@ def generate_block(store, rows=12):
     for i in range(rows):
         parity = i & 1
         nl, nd = (L1, D1) if parity == 0 else (L0, D0)
-        o += [f"ds_read_b32 v{nl}, %[addr] offset:{256 * (i + 1)}",   # next row's left
-              f"ds_read_b32 v{nd}, %[addr] offset:{256 * i}",         # this row's left = next row's diag
-              "s_waitcnt lgkmcnt(3)"]                                  # (see row(): two reads needed, three may fly)
+        # LDS ops retire in order; outstanding here, oldest first: this row's two reads (issued inside the previous
+        # row's body) and the previous row's write -> lgkmcnt(1) waits for the reads and lets the write fly
+        o += ["s_waitcnt lgkmcnt(1)" if i else "s_waitcnt lgkmcnt(0)"]
         b = body(parity)
+        # the prefetch of the next row's inputs (its left column entry, and this row's left = its diag) takes the
+        # body's first two wait slots
+        nops = [k for k, ln in enumerate(b) if ln == "s_nop 0"]
+        b[nops[0]] = f"ds_read_b32 v{nl}, %[addr] offset:{256 * (i + 1)}"
+        b[nops[1]] = f"ds_read_b32 v{nd}, %[addr] offset:{256 * i}"
         if i + 1 < rows:
             # the NEXT row's index goes where this row's last two wait states were (both lie behind the row's last
             # indexed read, and any instruction serves as a wait state): two issue slots less per row
