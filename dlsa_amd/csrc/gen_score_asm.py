@@ -143,7 +143,7 @@ def generate_block(store, rows=12):
     with one s_bfe, every LDS / global offset an immediate (the addresses move once per block, in the kernel).
     Same registers and the same entry / exit contract as generate(); only blocks shorter than `rows` (the last one
     of a query) go through the loop form."""
-    assert rows % 2 == 0 and 256 * (rows + 1) < 65536 and 256 * rows < 4096
+    assert rows % 2 == 0 and 256 * (rows + 1) < 65536 and 256 * (rows - 1) < 4096
     o = ["s_mov_b32 %[m0s], m0",
          f"v_mov_b32_e32 v{D0}, %[diag]",
          f"ds_read_b32 v{L0}, %[addr]",
