@@ -76,11 +76,15 @@ func (w *Worker) ExecuteWorkGPU(work *CompleteWorkPackage, queries []QueryTarget
 	index := make(map[SequenceId]C.uint32_t, len(work.Sequences))
 	nSeq := len(work.Sequences)
 	seqs := (*[1 << 30]*C.char)(C.malloc(C.size_t(nSeq) * C.size_t(unsafe.Sizeof((*C.char)(nil)))))[:nSeq:nSeq]
-	defer C.free(unsafe.Pointer(&seqs[0]))
 	i := 0
+	defer func() { // (one deferred call, not one per sequence: a package holds 10^5 of them)
+		for k := 0; k < i; k++ {
+			C.free(unsafe.Pointer(seqs[k]))
+		}
+		C.free(unsafe.Pointer(&seqs[0]))
+	}()
 	for id, s := range work.Sequences {
 		seqs[i] = C.CString(string(s))
-		defer C.free(unsafe.Pointer(seqs[i]))
 		index[id] = C.uint32_t(i)
 		i++
 	}
