@@ -1115,7 +1115,7 @@ int exact_one_fixed(Context& c, HostArena& arena, const uint16_t* qsym, uint32_t
   e.bnd = (int32_t*)(d_zero + z_bnd);
   e.bnd_pitch = maxcol + 2;
   e.dirs = nullptr;
-  e.nkb = exact_nsteps(maxcol) / 16;
+  e.nkb = exact_nsteps(maxcol, Q, rpl) / 16;
   e.ops = nullptr;
   e.first_unit = 0;
   e.n_units = n_units;

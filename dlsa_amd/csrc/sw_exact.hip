@@ -153,7 +153,7 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
   const uint32_t Q = P.Q, T = P.T;
   const uint32_t maxcol = P.Tlim > P.T0 ? P.Tlim : P.T0;
   const uint32_t mincol = P.Tlim < P.T0 ? P.Tlim : P.T0;
-  const uint32_t NG = exact_nsteps(maxcol) / 16;  // 16-step blocks
+  const uint32_t NG = exact_nsteps(maxcol, Q, RPL) / 16;  // 16-step blocks (== P.nkb)
   constexpr uint32_t SH = 64 * RPL;
   const uint32_t nstrips = exact_nstrips(Q, RPL);
 

@@ -93,12 +93,18 @@ struct ExactOut {
 // submission (exact_choose_rpl): 4 does the least work per cell (batches of many pairs), smaller strips give a
 // single long pair more waves and a shorter step.
 
-// steps per strip (multiple of 16: lane 63 reaches column maxcol at step maxcol + 62) for a pair whose widest
-// row has `maxcol` columns
-__host__ __device__ inline uint32_t exact_nsteps(uint32_t maxcol) { return maxcol == 0 ? 0 : ((maxcol + 63 + 15) / 16) * 16; }
+// steps per strip (multiple of 16) for a pair of Q rows whose widest row has `maxcol` columns: lane l reaches column
+// maxcol at step maxcol + l - 1.  A pair of several strips needs all 64 lanes of every strip (the last lane hands the
+// bottom row to the next strip); a pair that fits ONE strip stops with its last lane that holds a row -- a 150-row
+// read on 4 rows per lane uses 38 lanes and 192 steps instead of 224.
 __host__ __device__ inline uint32_t exact_nstrips(uint32_t Q, int rpl) { return (Q + 64 * rpl - 1) / (64 * rpl); }
+__host__ __device__ inline uint32_t exact_nsteps(uint32_t maxcol, uint32_t Q, int rpl) {
+  if (maxcol == 0) return 0;
+  const uint32_t lanes = Q > 64u * (uint32_t)rpl ? 64u : (Q + (uint32_t)rpl - 1) / (uint32_t)rpl;
+  return ((maxcol + (lanes ? lanes : 1u) - 1 + 15) / 16) * 16;
+}
 inline size_t exact_dir_words(uint32_t Q, uint32_t maxcol, int rpl) {
-  return (size_t)exact_nstrips(Q, rpl) * (exact_nsteps(maxcol) / 16) * rpl * 64;
+  return (size_t)exact_nstrips(Q, rpl) * (exact_nsteps(maxcol, Q, rpl) / 16) * rpl * 64;
 }
 
 // best cell of one strip (the last strip of a pair to finish combines them)

@@ -373,7 +373,7 @@ int exact_chunk_begin(Context& c, Workspace& ws, const PairSpec* specs, size_t b
       e.straight = pp.straight;
       const uint32_t maxcol = std::max(pp.Tlim, pp.T0);
       e.bnd_pitch = maxcol + 2;
-      e.nkb = exact_nsteps(maxcol) / 16;
+      e.nkb = exact_nsteps(maxcol, s.Q, rpl) / 16;
       e.n_units = std::max<uint32_t>(exact_nstrips(s.Q, rpl), 1);
       if (want_trace) dirw[i] = exact_dir_words(s.Q, maxcol, rpl);
     }
@@ -613,7 +613,7 @@ int exact_choose_rpl(const PairSpec* specs, size_t n, int simds) {
     for (size_t k = 0; k < n; k++) {
       const uint32_t st = std::max<uint32_t>(exact_nstrips(specs[k].Q, rpls[i]), 1);
       waves += st;
-      t = std::max(t, (double)exact_nsteps(specs[k].T) * tstep[i] + st * lag[i]);
+      t = std::max(t, (double)exact_nsteps(specs[k].T, specs[k].Q, rpls[i]) * tstep[i] + st * lag[i]);
       if (waves > (uint64_t)simds) break;
     }
     if (i > 0 && waves > (uint64_t)simds) break;  // the GPU is full: stay with the larger strips
