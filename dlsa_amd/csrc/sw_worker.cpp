@@ -222,6 +222,11 @@ float sw_benchmark_rust(double threshold_seconds, int q_steps, int t_steps) {
   float cups = 0;
   if (!run_once(64, 256, el, cups)) return 0.0f;  // device + code object warm-up, not part of the protocol
   for (;;) {
+    // every size twice, the second run counts: the library sizes its scratch buffers (device ring, pinned staging,
+    // host buffers) to the largest submission seen, and a worker that has just started would otherwise stop
+    // doubling at the first size whose ALLOCATION takes 10 ms and register a latency-bound figure (first call of
+    // a process 167 GCUPS, every later one 770)
+    if (!run_once(nQ, nT, el, cups)) return 0.0f;
     if (!run_once(nQ, nT, el, cups)) return 0.0f;
     if (el > threshold_seconds) break;
     if (nT >= ((size_t)1 << 27)) break;  // bound the scratch memory of one pair (the reference has no bound)
@@ -232,6 +237,7 @@ float sw_benchmark_rust(double threshold_seconds, int q_steps, int t_steps) {
   float sum = 0;
   for (int iT = 0; iT < t_steps; iT++)
     for (int iQ = 0; iQ < q_steps; iQ++) {
+      if (!run_once(nQ << iQ, nT << iT, el, cups)) return 0.0f;  // (untimed, as above)
       if (!run_once(nQ << iQ, nT << iT, el, cups)) return 0.0f;
       sum += cups;
     }
