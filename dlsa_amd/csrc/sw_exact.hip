@@ -31,6 +31,16 @@ namespace {
 
 // rows per lane (RPL): 4, 2 or 1, chosen per launch (ExactWork::rpl)
 
+// The pointers of an ExactPair are loaded from memory, so the compiler takes them for generic (flat) addresses; a flat
+// access counts on lgkmcnt as well as vmcnt, which makes every wait for LDS or scalar data also wait for the stores
+// in flight.  They all point to device memory: say so.
+template <class T>
+using gptr = __attribute__((address_space(1))) T*;
+template <class T>
+__device__ __forceinline__ gptr<T> glb(T* p) {
+  return (gptr<T>)p;
+}
+
 __device__ __forceinline__ int dpp_wave_shr1(int fill_lane0, int v) {
   // lane i <- lane i-1; lane 0 keeps `fill_lane0` (bound_ctrl = 0)
   return __builtin_amdgcn_update_dpp(fill_lane0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
@@ -157,8 +167,11 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
   constexpr uint32_t SH = 64 * RPL;
   const uint32_t nstrips = exact_nstrips(Q, RPL);
 
-  const int32_t* bin = P.bnd + (size_t)(strip > 0 ? strip - 1 : 0) * P.bnd_pitch;  // bottom row of strip-1
-  int32_t* bout = P.bnd + (size_t)strip * P.bnd_pitch;
+  const gptr<const int32_t> bin = glb((const int32_t*)P.bnd) + (size_t)(strip > 0 ? strip - 1 : 0) * P.bnd_pitch;  // bottom row of strip-1
+  const gptr<int32_t> bout = glb(P.bnd) + (size_t)strip * P.bnd_pitch;
+  const auto gq = glb(P.q);
+  const auto gt = glb(P.t);
+  const auto gleft = glb(P.left);
   const bool chained = strip > 0;
   const bool feeds = strip + 1 < nstrips;
   const bool plain = miss < 0 && gap < 0;          // MASK = false is legal in the interior
@@ -171,8 +184,8 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
   for (int r = 0; r < RPL; r++) {
     uint32_t i = ibase + r;
     valid[r] = i < Q;
-    qs[r] = valid[r] ? P.q[i] : 0x10000u;  // never equals a u16 symbol
-    leftv[r] = (WIN && valid[r]) ? (int)((P.left[(size_t)i * 64] >> P.left_shift) & 0xffffu) : 0;
+    qs[r] = valid[r] ? gq[i] : 0x10000u;  // never equals a u16 symbol
+    leftv[r] = (WIN && valid[r]) ? (int)((gleft[(size_t)i * 64] >> P.left_shift) & 0xffffu) : 0;
     h[r] = leftv[r];  // lane 0 starts at column 1 and never passes through column 0: its `left` is the boundary now
     bestv[r] = 0;
     bestj[r] = 0;
@@ -182,7 +195,7 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
   const uint32_t lim0 = row1_lane ? P.T0 : P.Tlim;  // column limit of this lane's row r == 0
   // ... and so is its first diagonal: H(row above lane 0's first row, col0).  (The other lanes get both through the
   // wavefront: every lane above them is forced to the boundary column when it passes column 0.)
-  int top_prev = (WIN && lane == 0 && ibase > 0) ? (int)((P.left[(size_t)(ibase - 1) * 64] >> P.left_shift) & 0xffffu) : 0;
+  int top_prev = (WIN && lane == 0 && ibase > 0) ? (int)((gleft[(size_t)(ibase - 1) * 64] >> P.left_shift) & 0xffffu) : 0;
   int last_out = h[RPL - 1];  // lane 1's first diagonal is lane 0's last row at column 0: the boundary again
   int hist[16];
   int tcur = 0x20000;
@@ -196,7 +209,7 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
   };
   auto fetch_t = [&](uint32_t g) -> int {
     const uint32_t col = g * 16 + (lane & 15) + 1;
-    return (col <= T) ? (int)P.t[col - 1] : 0x20000;
+    return (col <= T) ? (int)gt[col - 1] : 0x20000;
   };
   int bnext = fetch_bnd(0), tnext = fetch_t(0);
   for (uint32_t g = 0; g < NG; g++) {
@@ -223,7 +236,7 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
       exact_steps16<RPL, DIRS, true, WIN>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
                                 match, miss, gap, lim0, P.Tlim, leftv);
     if (DIRS) {
-      uint32_t* w = P.dirs + ((size_t)(strip * P.nkb + g) * RPL) * 64 + lane;
+      const gptr<uint32_t> w = glb(P.dirs) + ((size_t)(strip * P.nkb + g) * RPL) * 64 + lane;
 #pragma unroll
       for (int r = 0; r < RPL; r++) w[r * 64] = acc[r];
     }
@@ -347,7 +360,10 @@ __global__ void __launch_bounds__(64) sw_exact_kernel(ExactWork W, int match, in
 // symbols and the matching target range in LDS and walks inside it with wave-uniform (scalar) state; within a
 // strip the step index k = j - 1 + lane(row) never increases along the walk, so a window is left only downwards
 // or when the path crosses into the strip above.
-constexpr uint32_t WKB = 16;  // 16-step blocks per window
+#ifndef SW_WALK_WKB
+#define SW_WALK_WKB 16
+#endif
+constexpr uint32_t WKB = SW_WALK_WKB;  // 16-step blocks per window
 template <int RPL>
 __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, ExactOut* outs, uint32_t n,
                                                      int match, int miss, int gap) {
@@ -361,6 +377,9 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
   if (p >= n) return;
   const ExactPair P = pairs[p];
   if (!P.dirs || !P.ops) return;
+  const auto gq = glb(P.q);
+  const auto gt = glb(P.t);
+  const auto gops = glb(P.ops);
   if (outs[p].nops == 0xffffffffu) return;  // the fill kernel reported a hand-over time-out
   const bool resumed = P.walk_x != 0;  // continue a traceback that left the window to the right through its column 0
   int H = __builtin_amdgcn_readfirstlane(resumed ? P.walk_H : outs[p].score);
@@ -377,8 +396,16 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
     int jm1 = (int)bj - 1;
     bool go = true;
     bool tile_mode = false;    // how the path is followed inside a window: diagonal runs (below) or 7 x 7 tiles
+    const int pos_match = match > 0 ? match : 0, pos_miss = miss > 0 ? miss : 0, pos_gap = gap > 0 ? gap : 0;
     uint32_t diag_tiles = 0;
+#ifdef SW_WALK_COUNT
+    uint32_t c_stage = 0, c_tile = 0, c_run = 0, c_tmoves = 0, c_rmoves = 0;
+#define WCOUNT(x) x
+#else
+#define WCOUNT(x)
+#endif
     while (go) {
+      WCOUNT(c_stage++);
       // ---- stage a window: blocks [wbase, wtop] of this strip; all loads in flight before the first LDS write
       const uint32_t ktop = (uint32_t)jm1 + ((uint32_t)within >> LOG_RPL);
       const uint32_t wtop = ktop >> 4;
@@ -387,7 +414,7 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
       const int tbase = (int)(wbase * 16) - 63;  // wt[i] = t[tbase + i]
       __syncthreads();  // (one wave: orders the LDS reads of the old window before the overwrite)
       {
-        const uint32_t* src = P.dirs + ((size_t)(strip * P.nkb + wbase) * RPL) * 64 + lane;
+        const gptr<const uint32_t> src = glb((const uint32_t*)P.dirs) + ((size_t)(strip * P.nkb + wbase) * RPL) * 64 + lane;
         uint32_t v[WKB * RPL];
 #pragma unroll
         for (uint32_t u = 0; u < WKB * RPL; u++) {  // blocks past the window top are clamped (never read back)
@@ -398,12 +425,12 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
 #pragma unroll
         for (uint32_t u = 0; u < SH / 64; u++) {
           const uint32_t row = strip * SH + u * 64 + lane;
-          qv[u] = row < P.Q ? P.q[row] : 0x10000u;
+          qv[u] = row < P.Q ? gq[row] : 0x10000u;
         }
 #pragma unroll
         for (uint32_t u = 0; u < (WKB * 16 + 64) / 64; u++) {
           const int tj = tbase + (int)(u * 64 + lane);
-          tv[u] = (tj >= 0 && (uint32_t)tj < P.T) ? P.t[tj] : 0x20000u;
+          tv[u] = (tj >= 0 && (uint32_t)tj < P.T) ? gt[tj] : 0x20000u;
         }
 #pragma unroll
         for (uint32_t u = 0; u < WKB * RPL; u++)  // word u = (block u / RPL, row lane * RPL + u % RPL)
@@ -435,43 +462,81 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
           const int wr = within - dr, jt = jm1 - dc;
           const int kt = jt + (wr >> LOG_RPL);
           const bool valid = dr < 7 && dc < 7 && wr >= 0 && jt >= 0 && kt >= wlo;
-          uint32_t code = 0;
-          bool eq = false;
+          // (defaults of an invalid lane: code 0 and two symbols that differ, so the three masks below need no
+          // `valid &&` -- a bool carried out of the branch costs a v_cndmask + v_cmp pair per ballot)
+          uint32_t code = 0, qsym = 0x30000u, tsym = 0x40000u;
           if (valid) {
             const uint32_t w = wdir[(((uint32_t)kt >> 4) - wbase) * SH + (uint32_t)wr];
             code = (w >> ((~(uint32_t)kt & 15u) * 2)) & 3u;
-            eq = wq[wr] == wt[jt - tbase];
+            qsym = wq[wr];
+            tsym = wt[jt - tbase];
           }
           const uint64_t V = __builtin_amdgcn_ballot_w64(valid);
-          const uint64_t Dm = __builtin_amdgcn_ballot_w64(valid && (code & 1u));
-          const uint64_t Um = __builtin_amdgcn_ballot_w64(valid && (code & 2u));
-          const uint64_t EQ = __builtin_amdgcn_ballot_w64(eq);
-          uint64_t PM = 0;
-          for (uint32_t idx = 0; (V >> idx) & 1ull;) {  // (V has no bit in row 7 / column 7: idx stays below 64)
-            PM |= 1ull << idx;
-            idx += ((Dm >> idx) & 1ull) ? 9u : (((Um >> idx) & 1ull) ? 8u : 1u);
-          }
-          const uint64_t me = 1ull << lane;
-          const bool isd = (Dm & me) != 0, isu = !isd && (Um & me) != 0;
+          const uint64_t Dm = __builtin_amdgcn_ballot_w64((code & 1u) != 0);
+          const uint64_t Um = __builtin_amdgcn_ballot_w64(code >= 2u);
+          const uint64_t EQ = __builtin_amdgcn_ballot_w64(qsym == tsym);
+          // The path: a move adds 8 to the lane index if the cell's code is diagonal or up, and 1 if it is diagonal
+          // or left.  At most 13 cells of a 7 x 7 tile lie on one path (dr + dc grows with every move), so the loop
+          // is unrolled with not-taken exits: 7 scalar instructions per move, no taken branch before the end.
+          const uint64_t M8 = Dm | Um, M1 = Dm | ~Um;
+          uint64_t PM;
+          uint32_t pidx, ptmp;
+#define SW_WALK_MOVE                    \
+  "s_cbranch_scc0 .Ltile_end_%=\n\t"    \
+  "s_bitset1_b64 %[pm], %[idx]\n\t"     \
+  "s_bitcmp1_b64 %[m8], %[idx]\n\t"     \
+  "s_cselect_b32 %[tmp], 8, 0\n\t"      \
+  "s_bitcmp1_b64 %[m1], %[idx]\n\t"     \
+  "s_addc_u32 %[idx], %[idx], %[tmp]\n\t" \
+  "s_bitcmp1_b64 %[v], %[idx]\n\t"
+          asm volatile(
+              "s_mov_b64 %[pm], 0\n\t"
+              "s_mov_b32 %[idx], 0\n\t"
+              "s_bitcmp1_b64 %[v], 0\n\t" SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE
+                  SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE
+              ".Ltile_end_%=:"
+              : [pm] "=&s"(PM), [idx] "=&s"(pidx), [tmp] "=&s"(ptmp)
+              : [v] "s"(V), [m8] "s"(M8), [m1] "s"(M1)
+              : "scc");
+#undef SW_WALK_MOVE
+          const bool on_path = __builtin_amdgcn_inverse_ballot_w64(PM);
+          const bool isd = __builtin_amdgcn_inverse_ballot_w64(Dm);
+          const bool isu = !isd && __builtin_amdgcn_inverse_ballot_w64(Um);
           const uint64_t PD = PM & Dm, PE = PD & EQ, PG = PM & ~Dm;
-          auto upto = [&](uint64_t m) -> int {  // bits of m in lanes <= mine
-            return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) + ((m & me) ? 1 : 0);
+          auto below = [&](uint64_t m) -> int {  // bits of m in lanes < mine
+            return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
           };
-          const int ne = upto(PE), nd_ = upto(PD), ng = upto(PG);
-          const int h_after = H - match * ne - miss * (nd_ - ne) - gap * ng;  // H after this lane's move (path lanes)
-          const uint64_t stop = __builtin_amdgcn_ballot_w64((PM & me) && h_after <= 0);
-          const uint64_t T = stop ? (PM & ((2ull << __builtin_ctzll(stop)) - 1ull)) : PM;  // the moves taken
-          const uint32_t lt = 63u - (uint32_t)__builtin_clzll(T);                        // lane of the last one (T != 0)
-          uint32_t n = (uint32_t)__builtin_popcountll(T);
-          const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(T >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)T, 0u));
-          if (nops + n > cap) n = cap - nops;
-          if ((T & me) && rank < n) P.ops[nops + rank] = (uint8_t)(isd ? 0u : (isu ? 1u : 2u));
+          const int cE = __builtin_popcountll(PE), cD = __builtin_popcountll(PD), cG = __builtin_popcountll(PG);
+          uint32_t n = (uint32_t)(cD + cG);  // cells on the path
+          uint64_t T = PM;                   // the moves taken
+          // Walking back, only a move with a positive score lowers H.  If H stays positive even after all of them
+          // the walk cannot end inside this tile and everything but the op bytes is scalar: counts instead of prefix
+          // counts, and the position after the last move is the lane index the path loop stopped at.
+          if (H - pos_match * cE - pos_miss * (cD - cE) - pos_gap * cG > 0 && nops + n <= cap) {
+            H -= match * cE + miss * (cD - cE) + gap * cG;
+            if (on_path) gops[nops + (uint32_t)below(PM)] = (uint8_t)(isd ? 0u : (isu ? 1u : 2u));
+            within -= (int)(pidx >> 3);
+            jm1 -= (int)(pidx & 7u);
+          } else {
+            // H after this lane's move (meaningful in path lanes): the moves before it by prefix counts, its own by
+            // type (scores are 16-bit and counts <= 13: 24-bit multiplies)
+            const int own = isd ? (qsym == tsym ? match : miss) : gap;
+            const int h_after = H - own - __mul24(miss, below(PD)) - __mul24(match - miss, below(PE)) - __mul24(gap, below(PG));
+            const uint64_t stop = __builtin_amdgcn_ballot_w64(on_path && h_after <= 0);
+            if (stop) T = PM & ((2ull << __builtin_ctzll(stop)) - 1ull);
+            const uint32_t lt = 63u - (uint32_t)__builtin_clzll(T);  // lane of the last one (T != 0)
+            n = (uint32_t)__builtin_popcountll(T);
+            const uint32_t rank = (uint32_t)below(T);
+            if (nops + n > cap) n = cap - nops;
+            if (__builtin_amdgcn_inverse_ballot_w64(T) && rank < n) gops[nops + rank] = (uint8_t)(isd ? 0u : (isu ? 1u : 2u));
+            const int moved = (dr + ((isd || isu) ? 1 : 0)) | ((dc + ((isd || !isu) ? 1 : 0)) << 8);
+            const int mv = __builtin_amdgcn_readlane(moved, (int)lt);
+            H = __builtin_amdgcn_readlane(h_after, (int)lt);
+            within -= mv & 0xff;
+            jm1 -= mv >> 8;
+          }
           nops += n;
-          const int moved = (dr + ((isd || isu) ? 1 : 0)) | ((dc + ((isd || !isu) ? 1 : 0)) << 8);
-          const int mv = __builtin_amdgcn_readlane(moved, (int)lt);
-          H = __builtin_amdgcn_readlane(h_after, (int)lt);
-          within -= mv & 0xff;
-          jm1 -= mv >> 8;
+          WCOUNT(c_tile++; c_tmoves += n);
           // back to diagonal runs once two tiles in a row were crossed corner to corner
           diag_tiles = ((T & ~Dm) == 0 && n >= 7) ? diag_tiles + 1 : 0;
           if (diag_tiles >= 2) tile_mode = false;
@@ -506,7 +571,7 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
         const uint32_t L = ~run ? (uint32_t)__builtin_ctzll(~run) : 64u;  // diagonal moves from here
         const uint64_t eqm = __builtin_amdgcn_ballot_w64(eq);
         const int neq = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(eqm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)eqm, 0u));
-        const int h_before = H - match * neq - miss * ((int)lane - neq);  // H at lane t's cell if all before were diagonal
+        const int h_before = H - __mul24(match, neq) - __mul24(miss, (int)lane - neq);  // H at lane t's cell if all before were diagonal
         const int h_after = h_before - (eq ? match : miss);
         const uint64_t stop = __builtin_amdgcn_ballot_w64(lane < L && h_after <= 0);  // the walk ends where H reaches 0
         // branch-free bookkeeping (every taken branch costs a lone wave several issue slots)
@@ -522,8 +587,9 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
         uint32_t n = nd + (take_gap ? 1u : 0u);
         const uint32_t op = (take_gap && lane == n - 1) ? (up ? 1u : 2u) : 0u;
         if (nops + n > cap) n = cap - nops;
-        if (lane < n) P.ops[nops + lane] = (uint8_t)op;
+        if (lane < n) gops[nops + lane] = (uint8_t)op;
         nops += n;
+        WCOUNT(c_run++; c_rmoves += n);
         if (nd < 4 && take_gap) {  // direction changes every few cells: follow the path tile by tile
           tile_mode = true;
           diag_tiles = 0;
@@ -544,6 +610,9 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
         }
       }
     }
+#ifdef SW_WALK_COUNT
+    if (lane == 0 && nops > 1000) printf("walk: %u stages, %u tiles (%u moves), %u runs (%u moves)\n", c_stage, c_tile, c_tmoves, c_run, c_rmoves);
+#endif
     // where the walk stopped (row 1-based, window-local column; column 0 = the window's boundary column)
     end_x = (uint32_t)((int)(strip * SH) + within + 1);
     end_j = (uint32_t)(jm1 + 1);
