@@ -13,9 +13,10 @@
 // Arithmetic: int32 (the "int32 re-run" of the north star; equal to the reference's wrapping i16 on its
 // safe domain max H <= 32767).
 //
-// Direction bits, per cell: bit0 = (diag + s >= max(up, left) + gap), bit1 = (up >= left).  With H > 0
-// this is exactly the reference's if/else-if chain: diagonal first, then (x-1, j), then (x, j-1).  The
-// walker knows H along the path (it subtracts what each step added), so no "zero" code is needed.
+// Direction code, per cell, two bits: 3 = H came from the diagonal, 2 = from (x-1, j), 1 = from (x, j-1), with the
+// reference's if/else-if priority among equal candidates (diagonal first, then up, then left); it falls out of the
+// cell's v_max3 (see "arithmetic of one cell").  The walker knows H along the path (it subtracts what each step
+// added), so no "zero" code is needed: 0 appears only where H = 0, and the walk stops there.
 // Layout: word[((strip * nkb + k/16) * RPL + r) * 64 + lane], step k of that lane in bits
 // [2*(15 - k%16), +2); lane's row i = strip*256 + lane*RPL + r, its column at step k is j = k - lane + 1.
 #include "sw_internal.h"
@@ -46,6 +47,33 @@ __device__ __forceinline__ int dpp_wave_shr1(int fill_lane0, int v) {
   return __builtin_amdgcn_update_dpp(fill_lane0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
+// lane i <- lane (i + K) mod 16 of its row of 16 lanes (row_ror:(16 - K)); K = 0 is the value itself
+template <int K>
+__device__ __forceinline__ int row_rol(int v) {
+  if constexpr (K == 0) return v;
+  else return __builtin_amdgcn_update_dpp(0, v, 0x120 + (16 - K), 0xf, 0xf, true);  // (bound_ctrl: no "old" value to set up)
+}
+__device__ __forceinline__ int row_elem_to_lane0(int v, int k) {  // k is a constant after unrolling
+  switch (k & 15) {
+    case 0: return row_rol<0>(v);
+    case 1: return row_rol<1>(v);
+    case 2: return row_rol<2>(v);
+    case 3: return row_rol<3>(v);
+    case 4: return row_rol<4>(v);
+    case 5: return row_rol<5>(v);
+    case 6: return row_rol<6>(v);
+    case 7: return row_rol<7>(v);
+    case 8: return row_rol<8>(v);
+    case 9: return row_rol<9>(v);
+    case 10: return row_rol<10>(v);
+    case 11: return row_rol<11>(v);
+    case 12: return row_rol<12>(v);
+    case 13: return row_rol<13>(v);
+    case 14: return row_rol<14>(v);
+    default: return row_rol<15>(v);
+  }
+}
+
 // Discovery order of the reference as one integer: the cell with the SMALLER key is found first among
 // cells of equal H.  x and j are 1-based and < 2^31.
 __device__ __forceinline__ uint64_t order_key(uint32_t x, uint32_t j, uint32_t T, uint32_t phaseQp,
@@ -67,21 +95,32 @@ __device__ __forceinline__ uint64_t order_key(uint32_t x, uint32_t j, uint32_t T
 // re-polls only if a tag is still missing.  A dword store is atomic, so a tagged word is a complete value.
 constexpr uint32_t kTag = 0x80000000u;
 
-// Two direction bits of one cell appended to the lane's accumulator: acc = acc * 4 + 2 * (a1 >= b1) + (a0 == b0).
-// v_cmp into an SGPR pair + v_addc (acc + acc + carry) is one instruction per bit instead of cndmask + shift + or.
-// The compiler cannot see inside the statement, so the two wait states gfx950 needs between a VALU write of an
-// SGPR and a VALU read of it are provided here: each v_addc is two issue slots behind its v_cmp.
-__device__ __forceinline__ uint32_t push_dir_bits(uint32_t acc, int a1, int b1, int a0, int b0) {
-  uint64_t m1, m0;
-  asm("v_cmp_ge_i32 %1, %3, %4\n\t"
-      "v_cmp_eq_u32 %2, %5, %6\n\t"
-      "s_nop 0\n\t"
-      "v_addc_co_u32 %0, vcc, %0, %0, %1\n\t"
-      "v_addc_co_u32 %0, vcc, %0, %0, %2"
-      : "+v"(acc), "=&s"(m1), "=&s"(m0)
-      : "v"(a1), "v"(b1), "v"(a0), "v"(b0)
-      : "vcc");
-  return acc;
+// ---- arithmetic of one cell ---------------------------------------------------------------------------------
+// H is kept times four with a two-bit TAG in the low bits of each of the three candidates: 3 = diagonal, 2 = up
+// (x-1, j), 1 = left (x, j-1).  One v_max3 then yields the new H and, in its low bits, WHICH candidate won with the
+// reference's priority among equal values (diagonal first, then up, then left: rust/src/algorithm/mod.rs:665-706) --
+// the direction code costs no comparison.  Per cell: select + add (diag + s, constants pre-tagged), one saturating
+// subtract each for left and up (4 |gap| minus the tag; saturation at 0 is the max(., 0) of the recurrence, so the
+// result needs no clamp), v_max3, one AND to clear the tag, shift + v_bfi to append the code to the lane's
+// direction word.  Code 0 appears only where H = 0, where the walker never looks (it stops when H reaches 0).
+// H * 4 must stay below 2^31 (bit 31 is the hand-over tag): the host refuses pairs whose score could reach 2^29.
+struct CellConsts {
+  int match4, miss4;     // 4 * score + 3
+  int left4, up4;        // 4 * gap + 1, 4 * gap + 2 (signed form, masked variant)
+  uint32_t lsub, usub;   // -4 * gap - 1, -4 * gap - 2 (saturating form, gap < 0)
+};
+__device__ __forceinline__ CellConsts cell_consts(int match, int miss, int gap) {
+  CellConsts c;
+  c.match4 = 4 * match + 3;
+  c.miss4 = 4 * miss + 3;
+  c.left4 = 4 * gap + 1;
+  c.up4 = 4 * gap + 2;
+  c.lsub = (uint32_t)(-4 * gap - 1);
+  c.usub = (uint32_t)(-4 * gap - 2);
+  return c;
+}
+__device__ __forceinline__ int sat_sub(int a, uint32_t b) {  // max(a - b, 0) for a >= 0: v_sub_u32 clamp
+  return (int)__builtin_elementwise_sub_sat((uint32_t)a, b);
 }
 
 // One 256-row strip of one pair per WAVE.  Tickets are drawn strip level by level (every pair's strip 0, then
@@ -98,32 +137,36 @@ __device__ __forceinline__ uint32_t push_dir_bits(uint32_t acc, int a1, int b1, 
 // a real cell's, so they never win the maximum.  MASK = true handles the right edge and odd scorings.
 // WIN = true: the pair is a window with a known boundary column on its left (P.left); compiled separately so that
 // the whole-matrix path keeps exactly its registers and instructions.
+// All H values in here (h, top, boundary, leftv, bestv) are times four, tag bits clear.
 template <int RPL, bool DIRS, bool MASK, bool WIN>
 __device__ __forceinline__ void exact_steps16(const uint32_t (&qs)[RPL], const bool (&valid)[RPL], int (&h)[RPL],
                                               int (&bestv)[RPL], uint32_t (&bestj)[RPL], uint32_t (&acc)[RPL],
                                               int& top_prev, int& last_out, int& tcur, int (&hist)[16], int& jv,
-                                              int bcur, int tblk, int match, int miss, int gap, uint32_t lim0,
+                                              int bcur, int tblk, const CellConsts& C, uint32_t lim0,
                                               uint32_t Tlim, const int (&leftv)[RPL]) {
 #pragma unroll
   for (int k4 = 0; k4 < 16; k4++) {
-    const int s_b = __builtin_amdgcn_readlane(bcur, k4);
-    const int s_t = __builtin_amdgcn_readlane(tblk, k4);
+    // lane 0 takes element k4 of the block's boundary values / target symbols (held by lanes 0..15): a row rotate
+    // puts it there, the wave shift then overwrites every lane but lane 0
+    const int s_b = row_elem_to_lane0(bcur, k4);
+    const int s_t = row_elem_to_lane0(tblk, k4);
     const int top = dpp_wave_shr1(s_b, last_out);  // H(row above this lane, column j)
     tcur = dpp_wave_shr1(s_t, tcur);               // target symbol of column j
-    // everything that does not depend on this step's cell above: diag + s, left + gap, their max with 0
-    int d[RPL], lfg[RPL], m[RPL];
+    // everything that does not depend on this step's cell above: diag + s, left + gap
+    int d[RPL], lfg[RPL];
 #pragma unroll
     for (int r = 0; r < RPL; r++) {
-      const int sc = ((int)qs[r] == tcur) ? match : miss;
+      const int sc = ((int)qs[r] == tcur) ? C.match4 : C.miss4;
       d[r] = (r == 0 ? top_prev : h[r - 1]) + sc;
-      lfg[r] = h[r] + gap;
-      m[r] = max(max(d[r], lfg[r]), 0);
+      lfg[r] = MASK ? h[r] + C.left4 : sat_sub(h[r], C.lsub);
     }
-    // the dependent chain down the lane's rows: two operations per cell
-    int upg = top + gap;
+    // the dependent chain down the lane's rows
+    int upg = MASK ? top + C.up4 : sat_sub(top, C.usub);
 #pragma unroll
     for (int r = 0; r < RPL; r++) {
-      int hn = max(m[r], upg);
+      int ht = max(max(d[r], lfg[r]), upg);  // tagged
+      if (MASK) ht = max(ht, 0);
+      int hn = ht & ~3;
       int hb = hn;  // what competes for the best cell
       if (MASK) {
         const uint32_t lim = (r == 0) ? lim0 : Tlim;
@@ -139,14 +182,11 @@ __device__ __forceinline__ void exact_steps16(const uint32_t (&qs)[RPL], const b
           hb = hn;
         }
       }
-      if (DIRS) {
-        // bit 1: up >= left; bit 0: the diagonal wins (for H > 0: H == diag + s  <=>  diag + s >= max(up, left) + gap)
-        acc[r] = push_dir_bits(acc[r], upg, lfg[r], hn, d[r]);
-      }
+      if (DIRS) acc[r] = (acc[r] << 2) | ((uint32_t)ht & 3u);  // (a masked cell's code is never read)
       if (hb > bestv[r]) bestj[r] = (uint32_t)jv;  // strict: the first (smallest j) maximal cell of the row
       bestv[r] = max(bestv[r], hb);
       h[r] = hn;
-      upg = hn + gap;
+      upg = MASK ? hn + C.up4 : sat_sub(hn, C.usub);
     }
     top_prev = top;
     last_out = h[RPL - 1];
@@ -175,6 +215,7 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
   const bool chained = strip > 0;
   const bool feeds = strip + 1 < nstrips;
   const bool plain = miss < 0 && gap < 0;          // MASK = false is legal in the interior
+  const CellConsts C = cell_consts(match, miss, gap);
   const uint32_t ibase = strip * SH + lane * RPL;  // 0-based first row of this lane
   uint32_t qs[RPL];
   bool valid[RPL];
@@ -185,7 +226,7 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
     uint32_t i = ibase + r;
     valid[r] = i < Q;
     qs[r] = valid[r] ? gq[i] : 0x10000u;  // never equals a u16 symbol
-    leftv[r] = (WIN && valid[r]) ? (int)((gleft[(size_t)i * 64] >> P.left_shift) & 0xffffu) : 0;
+    leftv[r] = (WIN && valid[r]) ? 4 * (int)((gleft[(size_t)i * 64] >> P.left_shift) & 0xffffu) : 0;  // (times four, like every H here)
     h[r] = leftv[r];  // lane 0 starts at column 1 and never passes through column 0: its `left` is the boundary now
     bestv[r] = 0;
     bestj[r] = 0;
@@ -195,7 +236,7 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
   const uint32_t lim0 = row1_lane ? P.T0 : P.Tlim;  // column limit of this lane's row r == 0
   // ... and so is its first diagonal: H(row above lane 0's first row, col0).  (The other lanes get both through the
   // wavefront: every lane above them is forced to the boundary column when it passes column 0.)
-  int top_prev = (WIN && lane == 0 && ibase > 0) ? (int)((gleft[(size_t)(ibase - 1) * 64] >> P.left_shift) & 0xffffu) : 0;
+  int top_prev = (WIN && lane == 0 && ibase > 0) ? 4 * (int)((gleft[(size_t)(ibase - 1) * 64] >> P.left_shift) & 0xffffu) : 0;
   int last_out = h[RPL - 1];  // lane 1's first diagonal is lane 0's last row at column 0: the boundary again
   int hist[16];
   int tcur = 0x20000;
@@ -231,10 +272,10 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
     // reaches column 1 at step 63)
     if (plain && g * 16 + 16 <= mincol && !(WIN && g < 4))
       exact_steps16<RPL, DIRS, false, WIN>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
-                                 match, miss, gap, lim0, P.Tlim, leftv);
+                                 C, lim0, P.Tlim, leftv);
     else
       exact_steps16<RPL, DIRS, true, WIN>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
-                                match, miss, gap, lim0, P.Tlim, leftv);
+                                C, lim0, P.Tlim, leftv);
     if (DIRS) {
       const gptr<uint32_t> w = glb(P.dirs) + ((size_t)(strip * P.nkb + g) * RPL) * 64 + lane;
 #pragma unroll
@@ -263,8 +304,9 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
 #pragma unroll
   for (int r = 0; r < RPL; r++) {
     const uint64_t key = order_key(ibase + r + 1, bestj[r] + P.col0, P.Tfull ? P.Tfull : T, P.phaseQp, P.straight);
-    if (bestv[r] > gbv || (bestv[r] == gbv && bestv[r] > 0 && key < gkey)) {
-      gbv = bestv[r];
+    const int bv = bestv[r] >> 2;
+    if (bv > gbv || (bv == gbv && bv > 0 && key < gkey)) {
+      gbv = bv;
       gkey = key;
     }
   }
@@ -472,8 +514,8 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
             tsym = wt[jt - tbase];
           }
           const uint64_t V = __builtin_amdgcn_ballot_w64(valid);
-          const uint64_t Dm = __builtin_amdgcn_ballot_w64((code & 1u) != 0);
-          const uint64_t Um = __builtin_amdgcn_ballot_w64(code >= 2u);
+          const uint64_t Dm = __builtin_amdgcn_ballot_w64(code == 3u);
+          const uint64_t Um = __builtin_amdgcn_ballot_w64(code == 2u);
           const uint64_t EQ = __builtin_amdgcn_ballot_w64(qsym == tsym);
           // The path: a move adds 8 to the lane index if the cell's code is diagonal or up, and 1 if it is diagonal
           // or left.  At most 13 cells of a 7 x 7 tile lie on one path (dr + dc grows with every move), so the loop
@@ -567,7 +609,7 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
           eq = wq[wr] == wt[jt - tbase];
         }
         const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
-        const uint64_t run = __builtin_amdgcn_ballot_w64(valid && (code & 1u));
+        const uint64_t run = __builtin_amdgcn_ballot_w64(valid && code == 3u);
         const uint32_t L = ~run ? (uint32_t)__builtin_ctzll(~run) : 64u;  // diagonal moves from here
         const uint64_t eqm = __builtin_amdgcn_ballot_w64(eq);
         const int neq = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(eqm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)eqm, 0u));
@@ -579,8 +621,8 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
         const bool take_gap = !stop && L < 64 && ((vmask >> (L & 63u)) & 1ull);  // the cell that ended the run is in reach
         const int h_run = __builtin_amdgcn_readlane(h_after, (int)(nd ? nd - 1 : 0));
         const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)code, (int)(L & 63u));
-        const bool up = take_gap && (c & 2u);
-        const bool left = take_gap && !(c & 2u);
+        const bool up = take_gap && c == 2u;
+        const bool left = take_gap && c != 2u;
         H = (nd ? h_run : H) - (take_gap ? gap : 0);
         within -= (int)nd + (up ? 1 : 0);
         jm1 -= (int)nd + (left ? 1 : 0);

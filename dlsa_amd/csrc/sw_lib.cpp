@@ -386,6 +386,10 @@ int exact_chunk_begin(Context& c, Workspace& ws, const PairSpec* specs, size_t b
     toff[i] = add_seq(s.t, s.T, s.tid);
     ExactPair& e = hp[i];
     if (unit_pair.size() + e.n_units > 0x7fffff00ull) return fail(SW_E_ARG, "too many strips in one submission");
+    // the exact kernel keeps 4 * H in an int32 whose top bit is its hand-over tag (sw_exact.hip); a window starts
+    // from int16 boundary values
+    const uint64_t step_up = (uint64_t)std::max(std::max((int)sc.match, (int)sc.miss), std::max((int)sc.gap, 1));
+    if (((uint64_t)s.Q + s.T) * step_up + 65536 >= (1ull << 29)) return fail(SW_E_ARG, "pair too long for this scoring: (Q + T) * largest score must stay below 2^29");
     e.first_unit = (uint32_t)unit_pair.size();
     unit_pair.insert(unit_pair.end(), e.n_units, (uint32_t)i);
     // temporarily store offsets in the pointer fields
@@ -593,7 +597,7 @@ size_t exact_pair_bytes(const PairSpec& sp, int rpl, bool want_trace) {
 
 // Rows per lane for a submission.  4 does the least work per cell and is used whenever the submission fills the
 // GPU anyway (>= one wave per SIMD).  For a few long pairs the strips of a pair form a pipeline in which strip
-// s + 1 trails strip s by a fixed lag, so the time is about steps * step time + strips * lag; smaller strips
+// s + 1 trails strip s by a fixed lag, so the time is about steps * step time + (strips - 1) * lag; smaller strips
 // shorten the step (fewer rows per lane) at the price of more strips.  Step times and lags (ns) as measured on
 // MI355X with T = 100 000.
 int exact_choose_rpl(const PairSpec* specs, size_t n, int simds) {
@@ -604,7 +608,7 @@ int exact_choose_rpl(const PairSpec* specs, size_t n, int simds) {
   }();
   if (forced) return forced;
   const int rpls[3] = {4, 2, 1};
-  const double tstep[3] = {154, 104, 78}, lag[3] = {16800, 11000, 9400};
+  const double tstep[3] = {129, 88, 65}, lag[3] = {14400, 9800, 8800};
   int best = 4;
   double best_t = 0;
   for (int i = 0; i < 3; i++) {
@@ -613,7 +617,7 @@ int exact_choose_rpl(const PairSpec* specs, size_t n, int simds) {
     for (size_t k = 0; k < n; k++) {
       const uint32_t st = std::max<uint32_t>(exact_nstrips(specs[k].Q, rpls[i]), 1);
       waves += st;
-      t = std::max(t, (double)exact_nsteps(specs[k].T, specs[k].Q, rpls[i]) * tstep[i] + st * lag[i]);
+      t = std::max(t, (double)exact_nsteps(specs[k].T, specs[k].Q, rpls[i]) * tstep[i] + (st - 1) * lag[i]);
       if (waves > (uint64_t)simds) break;
     }
     if (i > 0 && waves > (uint64_t)simds) break;  // the GPU is full: stay with the larger strips

@@ -43,7 +43,9 @@ const char *sw_hip_version(void);
 
 /* ---- wide score ----------------------------------------------------------------------------------- */
 /* The un-truncated int32 score of a Result returned by this library (struct Result carries 16 bits,
- * rust/header/sw.h:8).  Equal to (int16_t)result->score on the reference's i16-safe domain. */
+ * rust/header/sw.h:8).  Equal to (int16_t)result->score on the reference's i16-safe domain.  Every entry point
+ * computes in 32 bits and refuses (NULL / SW_E_ARG, message in sw_hip_last_error) a pair whose score could reach 2^29:
+ * (strlen(query) + strlen(target)) * max(match, mismatch, gap, 1) + 65536 must stay below 2^29. */
 int32_t sw_result_score32(const struct Result *result);
 
 /* ---- batch of independent pairs: what internal/worker/worker_impl.go:108-168 (ExecuteWork) does with

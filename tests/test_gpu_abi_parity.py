@@ -324,3 +324,19 @@ def test_long_pairs_strips_chained_across_the_gpu(oracle):
         assert (res.query, res.target) == (exp["q"], exp["t"])
         assert res.score == exp["score"] & 0xFFFF
         _verify_alignment(q, t, res, sc)
+
+
+@pytest.mark.gpu
+def test_pair_whose_score_could_leave_the_kernels_range_is_refused():
+    """The exact kernel keeps 4 * H in an int32 whose top bit is the hand-over tag (sw_exact.hip "arithmetic of one
+    cell"): a pair that could score 2^29 is an error, not a wrong answer.  (The reference computes in i16 and is
+    undefined far below that: rust/src/algorithm/mod.rs:66-202.)"""
+    import dlsa_amd
+    from dlsa_amd import bridge
+    sc = dlsa_amd.AlignmentScore(32767, -1, -1)
+    with pytest.raises(bridge.SwHipError, match="2\\^29"):
+        bridge.align_batch([b"A" * 9000], [b"A" * 9000], sc, 0)
+    # just inside: 2 * 8001 * 32767 + 65536 < 2^29, and the score is exact in 32 bits (one match per aligned column)
+    r = bridge.align_batch([b"A" * 8001], [b"A" * 8001], sc, 0)[0]
+    assert r is not None and len(r.query) >= 7900 and r.query == r.target
+    assert r.score32 == len(r.query) * 32767 and r.score == r.score32 & 0xffff
