@@ -50,7 +50,7 @@ def mad(dst, hsrc, r):
     return f"v_pk_mad_i16 {dst}, {hsrc}, %[one], {tab(r)} clamp"
 
 
-def cells4(r0, hl):
+def cells4(r0, hl, cols=16):
     """four cells r0..r0+3; d (v43) holds diag+s of cell r0 on entry and of cell r0+4 on exit"""
     h0, h1, h2, h3 = h(r0), h(r0 + 1), h(r0 + 2), h(r0 + 3)
     m, n, a, d = f"v{M}", f"v{N}", f"v{A}", f"v{D}"
@@ -74,7 +74,7 @@ def cells4(r0, hl):
         f"v_pk_max_i16 {h2}, {m}, {d}",
         "s_nop 0",
         f"v_pk_max_i16 {m}, {h2}, {h3}",
-    ] + ([mad(d, h3, r0 + 4)] if r0 + 4 < 16 else ["s_nop 0"]) + [
+    ] + ([mad(d, h3, r0 + 4)] if r0 + 4 < cols else ["s_nop 0"]) + [
         f"v_pk_sub_u16 {n}, {m}, %[g] clamp",
         f"v_pk_max_i16 %[best], %[best], {m}",
         f"v_pk_max_i16 {h3}, {n}, {a}",
@@ -82,16 +82,19 @@ def cells4(r0, hl):
     ]
 
 
-def body(parity):
+def body(parity, cols=16):
+    """one query row over the first `cols` columns of the strip (16, or 8 for the half-width form that a group's
+    last strip takes when its targets end within its first eight columns)"""
+    assert cols in (8, 16)
     left, diag = (f"v{L0}", f"v{D0}") if parity == 0 else (f"v{L1}", f"v{D1}")
     out = [mad(f"v{D}", diag, 0)]
-    out += cells4(0, left)
-    for r0 in (4, 8, 12):
-        out += cells4(r0, h(r0 - 1))
+    out += cells4(0, left, cols)
+    for r0 in range(4, cols, 4):
+        out += cells4(r0, h(r0 - 1), cols)
     return out
 
 
-def row(parity, store):
+def row(parity, store, cols=16):
     nl, nd = (L1, D1) if parity == 0 else (L0, D0)
     off = 256 * parity
     # LDS ops retire in order.  Outstanding here, oldest first: this row's two reads (issued one row ago), the
@@ -104,16 +107,17 @@ def row(parity, store):
          "s_and_b32 %[t], %[qw], 3",        # this row's nucleotide selects the table entry (index mode, SRC2)
          "s_set_gpr_idx_idx %[t]",
          "s_nop 0"]
-    o += body(parity) + ["s_lshr_b32 %[qw], %[qw], 2",
-                         f"ds_write_b32 %[waddr], {h(15)} offset:{off}"]
+    o += body(parity, cols) + ["s_lshr_b32 %[qw], %[qw], 2",
+                               f"ds_write_b32 %[waddr], {h(cols - 1)} offset:{off}"]
     if store:  # the wave whose last column feeds the next unit (another workgroup) through HBM
+        assert cols == 16
         o += [f"global_store_dword %[goff], {h(15)}, %[gb] sc1",
               "v_add_u32_e32 %[goff], 0x100, %[goff]"]
     return o
 
 
-def generate(store=False):
-    """the loop in one of its two forms: without / with the store of the wave's last column to global memory.
+def generate(store=False, cols=16):
+    """the loop in one of its forms: without / with the store of the wave's last column to global memory.
     The kernel picks the form per block outside the loop (one wave in 16 stores, and only in chained units); a
     test inside the loop cost every wave a scalar compare and a taken branch per row."""
     o = ["s_mov_b32 %[m0s], m0",                       # the compiler's M0 (LDS-DMA base) comes back at the exit
@@ -124,9 +128,9 @@ def generate(store=False):
          "s_set_gpr_idx_on %[t], gpr_idx(SRC2)",       # from here to Lexit a VALU third source is v[n + index]
          "s_waitcnt lgkmcnt(0)",
          "Ltop_%=:"]
-    o += row(0, store)
+    o += row(0, store, cols)
     o += ["s_sub_u32 %[i], %[i], 1", "s_cmp_eq_u32 %[i], 0", "s_cbranch_scc1 Lexit_%="]
-    o += row(1, store)
+    o += row(1, store, cols)
     o += ["v_add_u32_e32 %[addr], 0x200, %[addr]",
           "v_add_u32_e32 %[waddr], 0x200, %[waddr]",
           "s_sub_u32 %[i], %[i], 1", "s_cmp_lg_u32 %[i], 0", "s_cbranch_scc1 Ltop_%=",
@@ -138,7 +142,7 @@ def generate(store=False):
     return o
 
 
-def generate_block(store, rows=12):
+def generate_block(store, rows=12, cols=16):
     """a FULL block of `rows` query rows, unrolled: no loop counter, no taken branch, the row's nucleotide extracted
     with one s_bfe, every LDS / global offset an immediate (the addresses move once per block, in the kernel).
     Same registers and the same entry / exit contract as generate(); only blocks shorter than `rows` (the last one
@@ -159,7 +163,7 @@ def generate_block(store, rows=12):
         # LDS ops retire in order; outstanding here, oldest first: this row's two reads (issued inside the previous
         # row's body) and the previous row's write -> lgkmcnt(1) waits for the reads and lets the write fly
         o += ["s_waitcnt lgkmcnt(1)" if i else "s_waitcnt lgkmcnt(0)"]
-        b = body(parity)
+        b = body(parity, cols)
         # the prefetch of the next row's inputs (its left column entry, and this row's left = its diag) takes the
         # body's first two wait slots
         nops = [k for k, ln in enumerate(b) if ln == "s_nop 0"]
@@ -174,8 +178,9 @@ def generate_block(store, rows=12):
             nxt = index_of_row(i + 1)
             b[nops[-2]], b[nops[-1]] = nxt[0], nxt[1]
         o += b
-        o += [f"ds_write_b32 %[waddr], {h(15)} offset:{256 * i}"]
+        o += [f"ds_write_b32 %[waddr], {h(cols - 1)} offset:{256 * i}"]
         if store:
+            assert cols == 16
             o += [f"global_store_dword %[goff], {h(15)}, %[gb] offset:{256 * i} sc1"]
     if store:
         o += [f"v_add_u32_e32 %[goff], {hex(256 * rows)}, %[goff]"]
@@ -203,7 +208,9 @@ def counts():
     blk = generate_block(True)
     other = sum(1 for ln in blk if is_valu(ln) and not ln.startswith("v_pk_"))
     assert sum(1 for ln in blk if ln.startswith("v_pk_")) == 12 * packed and other == 3
-    return {"packed": packed, "snop": snop, "aux_x2": 0, "store": 0}
+    half = sum(1 for ln in body(0, 8) if ln.startswith("v_pk_"))
+    assert 2 * half == packed and len(body(1, 8)) == len(body(0, 8))
+    return {"packed": packed, "packed_half": half, "snop": snop, "aux_x2": 0, "store": 0}
 
 
 def render(Dslots=3, B=12):
@@ -217,11 +224,13 @@ def render(Dslots=3, B=12):
            f"#define SW_SCORE_ASM_AUX_PER_2ROWS {c['aux_x2']}    /* other VALU per two rows (none: unrolled block, immediate offsets) */\n",
            f"#define SW_SCORE_ASM_STORE_PER_ROW {c['store']}    /* extra VALU of a row that is also stored to HBM (none; one per stored block) */\n",
            f"#define SW_SCORE_ASM_SNOP_PER_ROW {c['snop']}\n",
+           f"#define SW_SCORE_ASM_PACKED_PER_HALF_ROW {c['packed_half']}   /* ... of the half-width forms (8 columns) */\n",
            ]
     n = 0
-    for name, store, full in (("SW_SCORE_ROWS_ASM", False, False), ("SW_SCORE_ROWS_STORE_ASM", True, False),
-                              ("SW_SCORE_BLOCK_ASM", False, True), ("SW_SCORE_BLOCK_STORE_ASM", True, True)):
-        lines = generate_block(store, B) if full else generate(store)
+    for name, store, full, cols in (("SW_SCORE_ROWS_ASM", False, False, 16), ("SW_SCORE_ROWS_STORE_ASM", True, False, 16),
+                                    ("SW_SCORE_BLOCK_ASM", False, True, 16), ("SW_SCORE_BLOCK_STORE_ASM", True, True, 16),
+                                    ("SW_SCORE_ROWS_HALF_ASM", False, False, 8), ("SW_SCORE_BLOCK_HALF_ASM", False, True, 8)):
+        lines = generate_block(store, B, cols) if full else generate(store, cols)
         n += len(lines)
         out.append(f"#define {name} \\\n")
         for ln in lines:

@@ -34,6 +34,7 @@ struct sw_db {
   ScoreGroup* d_groups = nullptr;
   uint32_t* d_elem_group = nullptr;  // per strip of the stream: its group
   uint32_t n_elems = 0;              // strips in the stream
+  uint32_t n_half_elems = 0;         // ... of which run the half-width row loop (ScoreGroup::last_cols <= 8)
   // ticket-ordered unit table, rebuilt when the lane count / ring geometry of a search differs (build_units)
   ScoreUnit* d_units = nullptr;
   uint32_t n_units = 0, units_S = 0, units_R = 0, units_W = 0;
@@ -70,6 +71,12 @@ struct DbDeleter {
   void operator()(sw_db* d) const { db_release(d); }
 };
 // The packed part of a database goes to the device (caller holds the context's lock, its device is current).
+// strips that run the half-width row loop: the last strip of a group whose targets all end within its first 8 columns
+void count_half_strips(sw_db* db) {
+  db->n_half_elems = 0;
+  for (const ScoreGroup& G : db->groups) db->n_half_elems += (G.last_cols >= 1 && G.last_cols <= kScoreR / 2);
+}
+
 bool db_upload(sw_db* db, const std::vector<uint32_t>& words, const std::vector<uint32_t>& lens,
                const std::vector<uint32_t>& elem_group) {
   const size_t ngroups = db->groups.size();
@@ -176,10 +183,11 @@ sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
     db->groups[g].strip_base = (uint32_t)total_strips;
     db->groups[g].nstrips = (maxlen + kScoreR - 1) / kScoreR;
     db->groups[g].first_slot = (uint32_t)(g * kGroupTargets);
-    db->groups[g].pad_ = 0;
+    db->groups[g].last_cols = maxlen ? maxlen - kScoreR * (db->groups[g].nstrips - 1) : 0;
     total_strips += db->groups[g].nstrips;
   }
   db->n_elems = (uint32_t)total_strips;
+  count_half_strips(db);
   // the strip stream: strip e = dwords [e*128, e*128+128), [half][lane], 16 residues (2 bits each) per dword
   std::vector<uint32_t> words(std::max<size_t>(total_strips * kGroupTargets, 1), 0);
   std::vector<uint32_t> elem_group(std::max<size_t>(total_strips, 1), 0);
@@ -348,6 +356,15 @@ sw_db* db_open_locked(Context* ctx, const char* path) {
     packed_res += lens[k];
   }
   if (packed_res != h.packed_residues) return bad("packed residue count mismatch");
+  // derived from the lengths, never taken from the file: the kernel picks its half-width row loop by it
+  for (size_t g = 0; g < db->groups.size(); g++) {
+    uint32_t maxlen = 0;
+    for (size_t k = g * kGroupTargets; k < (g + 1) * kGroupTargets && k < n_slots; k++) maxlen = std::max(maxlen, lens[k]);
+    ScoreGroup& G = db->groups[g];
+    const uint64_t before_last = (uint64_t)kScoreR * (G.nstrips - 1);
+    G.last_cols = maxlen > before_last ? (uint32_t)(maxlen - before_last) : 0;
+  }
+  count_half_strips(db);
   uint64_t gb = 0;
   for (uint32_t ti : db->generic) {
     if (ti >= h.n || db->packed_ok[ti] == 1 || db->packed_ok[ti] == 2) return bad("escape list names a bad sequence");
@@ -726,7 +743,8 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
   // what this launch executes, for the roofline arithmetic of bench.py (counted, not pasted: every strip of the
   // stream walks all Q query rows through the generated row loop; a unit that hands its last column to the next
   // unit also stores those Q rows to HBM, 256 bytes each, and the consumer reads them back once)
-  c.stats.score_strip_rows += (uint64_t)db->n_elems * Q;
+  // (in full-strip equivalents: a half-width strip executes half the packed instructions per row)
+  c.stats.score_strip_rows += ((uint64_t)2 * db->n_elems - db->n_half_elems) * Q / 2;
   c.stats.score_chain_rows += chained * Q;
   c.stats.score_workgroups = (uint32_t)nwg;
   return SW_OK;

@@ -149,7 +149,8 @@ struct ScoreGroup {       // one group of up to 128 length-sorted targets
   uint32_t strip_base;    // index of this group's first strip in the stream
   uint32_t nstrips;       // ceil(max length / 16)
   uint32_t first_slot;    // index of lane 0 / half 0 in the per-slot arrays (lens, scores); 128 slots
-  uint32_t pad_;
+  uint32_t last_cols;     // columns of the last strip that any target of the group reaches: max length - 16 * (nstrips
+                          // - 1), 1..16; <= 8: the strip runs the half-width row loop.  0 (unknown) = 16.
 };
 
 struct ScoreUnit {        // ticket t -> what to do (built per search on the host, see build_units)

@@ -183,7 +183,9 @@ struct sw_kernel_stats {
   /* what the score-kernel launches executed, counted by the library (no pasted constants in bench.py): */
   uint64_t score_strip_rows;   /* sum over launches of (16-column strips of the database) x (query rows): one
                                   iteration of the generated row loop each, score_packed_per_row packed VALU
-                                  wave-instructions + score_aux_per_2rows / 2 address increments */
+                                  wave-instructions + score_aux_per_2rows / 2 address increments.  The last strip of
+                                  a group whose targets all end within its first 8 columns runs the 8-column form of
+                                  the loop (half the instructions) and counts as half a strip */
   uint64_t score_chain_rows;   /* of those, rows also stored to the HBM boundary ring (256 B written once and
                                   read back once each): units that hand their last column to the next unit */
   uint32_t score_packed_per_row, score_aux_per_2rows; /* read off the generated loop (sw_score_asm.inc) */
