@@ -35,6 +35,7 @@ struct sw_db {
   uint32_t* d_elem_group = nullptr;  // per strip of the stream: its group
   uint32_t n_elems = 0;              // strips in the stream
   uint32_t n_half_elems = 0;         // ... of which run the half-width row loop (ScoreGroup::last_cols <= 8)
+  std::vector<uint32_t> len64;       // sorted distinct lengths of packed targets that are multiples of 64 (query batching)
   // ticket-ordered unit table, rebuilt when the lane count / ring geometry of a search differs (build_units)
   ScoreUnit* d_units = nullptr;
   uint32_t n_units = 0, units_S = 0, units_R = 0, units_W = 0;
@@ -72,9 +73,15 @@ struct DbDeleter {
 };
 // The packed part of a database goes to the device (caller holds the context's lock, its device is current).
 // strips that run the half-width row loop: the last strip of a group whose targets all end within its first 8 columns
-void count_half_strips(sw_db* db) {
+// ... and the lengths that are multiples of 64 (per-slot lengths `lens`, 0 = padding)
+void count_half_strips(sw_db* db, const std::vector<uint32_t>& lens) {
   db->n_half_elems = 0;
   for (const ScoreGroup& G : db->groups) db->n_half_elems += (G.last_cols >= 1 && G.last_cols <= kScoreR / 2);
+  db->len64.clear();
+  for (uint32_t len : lens)
+    if (len && len % 64 == 0) db->len64.push_back(len);
+  std::sort(db->len64.begin(), db->len64.end());
+  db->len64.erase(std::unique(db->len64.begin(), db->len64.end()), db->len64.end());
 }
 
 bool db_upload(sw_db* db, const std::vector<uint32_t>& words, const std::vector<uint32_t>& lens,
@@ -187,7 +194,7 @@ sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
     total_strips += db->groups[g].nstrips;
   }
   db->n_elems = (uint32_t)total_strips;
-  count_half_strips(db);
+  count_half_strips(db, lens);
   // the strip stream: strip e = dwords [e*128, e*128+128), [half][lane], 16 residues (2 bits each) per dword
   std::vector<uint32_t> words(std::max<size_t>(total_strips * kGroupTargets, 1), 0);
   std::vector<uint32_t> elem_group(std::max<size_t>(total_strips, 1), 0);
@@ -364,7 +371,7 @@ sw_db* db_open_locked(Context* ctx, const char* path) {
     const uint64_t before_last = (uint64_t)kScoreR * (G.nstrips - 1);
     G.last_cols = maxlen > before_last ? (uint32_t)(maxlen - before_last) : 0;
   }
-  count_half_strips(db);
+  count_half_strips(db, lens);
   uint64_t gb = 0;
   for (uint32_t ti : db->generic) {
     if (ti >= h.n || db->packed_ok[ti] == 1 || db->packed_ok[ti] == 2) return bad("escape list names a bad sequence");
@@ -622,9 +629,19 @@ bool fast_domain(Scoring sc) {
 // `arena` != nullptr: the allocation-free variant (sw_db_scores_noalloc) -- ws is the fixed workspace carved out
 // of the device's static scratch array, the unit table is built inside the pre-reserved host arena on every call
 // and the number of workgroups is cut down to what the fixed boundary ring can serve.
+// A batch of queries in one pass (ScoreParams::blkinfo): `batch` names the row blocks of the stacked queries, qwords
+// holds one word per block, Q is the length of one of them and ws.slot_scores receives one array per query.
+struct ScoreBatch {
+  const uint32_t* blkinfo;  // n_blocks + 1 words
+  uint32_t n_blocks, n_queries;
+  uint64_t rows;            // sum of the query lengths
+};
 int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwords, size_t n_qwords, uint32_t Q,
-                      Scoring sc, HostArena* arena = nullptr, bool persist = false) {
-  const uint32_t nblk = (Q + kScoreB - 1) / kScoreB;
+                      Scoring sc, HostArena* arena = nullptr, bool persist = false, const ScoreBatch* batch = nullptr) {
+  if (batch && (arena || persist || batch->n_blocks == 0 || n_qwords != (size_t)batch->n_blocks + 1))
+    return fail(SW_E_ARG, "internal: bad query batch");
+  const uint32_t nblk = batch ? batch->n_blocks : (Q + kScoreB - 1) / kScoreB;
+  const uint32_t n_sets = batch ? batch->n_queries : 1;
   const size_t Qpad = (size_t)nblk * kScoreB;
   const uint32_t W = (uint32_t)score_waves_per_group(db->n_elems, c.cus);
   uint32_t max_wg = (uint32_t)c.cus * (uint32_t)score_workgroups_per_cu((int)W);
@@ -634,7 +651,7 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
   // (swept 1..8192 on every shape of scratch/sweep.py: flat from ~512 up).  So: as many lanes as the database has
   // groups, up to 1024, as long as the boundary ring (one slot of Qpad x 256 B per unit in flight or waiting) stays
   // within twice the scratch budget; a database with few groups or a very long query falls back to chains.
-  const uint32_t nblk16 = (Q + 15) / 16;
+  const uint32_t nblk16 = batch ? (uint32_t)((Qpad + 15) / 16) : (Q + 15) / 16;
   // boundary ring: a workgroup has at most 1 + queue depth units in flight, fewer when a unit is long
   const uint32_t ahead = std::min<uint32_t>(score_queue_depth(), 48 / nblk16 + 1);
   uint32_t S, ring_slots;
@@ -700,15 +717,17 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
   const size_t gb_stride = Qpad * 64;
   int rc;
   if ((rc = ws.qwords.ensure(n_qwords * 4))) return rc;
-  if ((rc = ws.slot_scores.ensure(db->slot_target.size() * 4))) return rc;
+  if ((rc = ws.slot_scores.ensure(db->slot_target.size() * 4 * n_sets))) return rc;
+  if (batch && (rc = ws.blkinfo.ensure(((size_t)nblk + 1) * 4))) return rc;
   if ((rc = ws.gbound.ensure((size_t)(persist ? n_units : ring_slots) * gb_stride * 4))) return rc;
   if (persist && (rc = ws.strip_best.ensure(std::max<size_t>((size_t)db->n_elems * 256, 256)))) return rc;
   if ((rc = ws.ticket.ensure(256))) return rc;
   if ((rc = ws.prog.ensure(std::max<size_t>((size_t)n_units * 8, 16)))) return rc;
   HIPCK(hipMemcpyAsync(ws.qwords.p, qwords, n_qwords * 4, hipMemcpyHostToDevice, c.stream));
+  if (batch) HIPCK(hipMemcpyAsync(ws.blkinfo.p, batch->blkinfo, ((size_t)nblk + 1) * 4, hipMemcpyHostToDevice, c.stream));
   HIPCK(hipMemsetAsync(ws.ticket.p, 0, 256, c.stream));
   HIPCK(hipMemsetAsync(ws.prog.p, 0, std::max<size_t>((size_t)n_units * 8, 16), c.stream));
-  HIPCK(hipMemsetAsync(ws.slot_scores.p, 0, db->slot_target.size() * 4, c.stream));
+  HIPCK(hipMemsetAsync(ws.slot_scores.p, 0, db->slot_target.size() * 4 * n_sets, c.stream));
   ScoreParams p{};
   p.words = db->d_words;
   p.groups = db->d_groups;
@@ -732,6 +751,8 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
   p.match = sc.match;
   p.miss = sc.miss;
   p.gap = sc.gap;
+  p.blkinfo = batch ? (const uint32_t*)ws.blkinfo.p : nullptr;
+  p.n_blocks = batch ? nblk : 0;
   // a small database is a few chains of units: publish their boundary columns often (latency), a big one rarely
   // (in blocks; swept: 10 kb queries like 10 blocks, 1 kb queries 5 -- a short unit is over before a coarse
   // publication lets its consumer start)
@@ -744,14 +765,15 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
   // stream walks all Q query rows through the generated row loop; a unit that hands its last column to the next
   // unit also stores those Q rows to HBM, 256 bytes each, and the consumer reads them back once)
   // (in full-strip equivalents: a half-width strip executes half the packed instructions per row)
-  c.stats.score_strip_rows += ((uint64_t)2 * db->n_elems - db->n_half_elems) * Q / 2;
-  c.stats.score_chain_rows += chained * Q;
+  const uint64_t rows = batch ? batch->rows : Q;
+  c.stats.score_strip_rows += ((uint64_t)2 * db->n_elems - db->n_half_elems) * rows / 2;
+  c.stats.score_chain_rows += chained * rows;
   c.stats.score_workgroups = (uint32_t)nwg;
   return SW_OK;
 }
 
 // after the stream has been synchronised: error word + kernel time of the last score pass
-int score_pass_finish_locked(Context& c, sw_db* db, uint32_t Q, uint32_t kerr) {
+int score_pass_finish_locked(Context& c, sw_db* db, uint64_t Q, uint32_t kerr) {  // Q: query rows of the pass (summed over a batch)
   if (kerr) {
     static const char* const what[] = {"", "a wait for another workgroup's boundary column ran out of time",
                                        "a wait for a neighbouring wave ran out of time",
@@ -765,7 +787,7 @@ int score_pass_finish_locked(Context& c, sw_db* db, uint32_t Q, uint32_t kerr) {
   HIPCK(hipEventElapsedTime(&ms, c.ev0, c.ev1));
   c.stats.score_kernel_ms += ms;
   c.stats.score_launches += 1;
-  c.stats.score_cells += (uint64_t)Q * db->packed_residues;
+  c.stats.score_cells += Q * db->packed_residues;
   return SW_OK;
 }
 
@@ -853,6 +875,85 @@ bool g_host_topk = [] {
 }();
 constexpr uint32_t kTieCap = 65536;
 
+// Device-side selection (sw_topk.hip) over the per-slot scores of ONE query that a score pass left at d_slot: the
+// candidates above the k-th score, the ties at it and the slots that need an exact re-run come back, the re-runs
+// are done, and everything that can be among the k best lands in `pool`.  pass_rows != 0: this is the first
+// selection after the score pass -- its error word is fetched with the same synchronisation and the pass is
+// accounted (pass_rows = query rows of the pass).  done = false: the tie list overflowed (e.g. every target scores
+// the same); the caller takes the full download instead.
+int select_pool_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, Scoring sc, size_t k,
+                       const int32_t* d_slot, uint64_t pass_rows, std::vector<TopEntry>& pool, bool& done) {
+  done = false;
+  const uint32_t Q = (uint32_t)qp.d.sym.size();
+  const uint32_t n_slots = (uint32_t)db->slot_target.size();
+  int rc;
+  if ((rc = ws.sel_hist.ensure(32768 * 4))) return rc;
+  if ((rc = ws.sel_ctr.ensure(kSelWords * 4))) return rc;
+  if ((rc = ws.sel_rerun.ensure((size_t)n_slots * 4))) return rc;
+  if ((rc = ws.sel_cand.ensure(std::max<size_t>(k, 16) * 8))) return rc;
+  if ((rc = ws.sel_tie.ensure((size_t)kTieCap * 8))) return rc;
+  HIPCK(hipMemsetAsync(ws.sel_hist.p, 0, 32768 * 4, c.stream));
+  HIPCK(hipMemsetAsync(ws.sel_ctr.p, 0, kSelWords * 4, c.stream));
+  SelectParams sp{};
+  sp.slot_scores = d_slot;
+  sp.lens = db->d_lens;
+  sp.slot_target = db->d_slot_target;
+  sp.n_slots = n_slots;
+  sp.Q = Q;
+  sp.match = sc.match;
+  sp.k = (uint32_t)k;
+  sp.hist = (uint32_t*)ws.sel_hist.p;
+  sp.counters = (uint32_t*)ws.sel_ctr.p;
+  sp.rerun = (uint32_t*)ws.sel_rerun.p;
+  sp.rerun_cap = n_slots;
+  sp.cand = (uint32_t*)ws.sel_cand.p;
+  sp.cand_cap = (uint32_t)std::max<size_t>(k, 16);
+  sp.tie = (uint32_t*)ws.sel_tie.p;
+  sp.tie_cap = kTieCap;
+  HIPCK(launch_select(sp, c.stream));
+  uint32_t ctr[kSelWords] = {0};
+  uint32_t kerr = 0;
+  HIPCK(hipMemcpyAsync(ctr, ws.sel_ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, c.stream));
+  if (pass_rows) HIPCK(hipMemcpyAsync(&kerr, (uint32_t*)ws.ticket.p + 32, 4, hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipStreamSynchronize(c.stream));
+  if (pass_rows && (rc = score_pass_finish_locked(c, db, pass_rows, kerr))) return rc;
+  if (!(ctr[kSelTie] <= kTieCap && ctr[kSelCand] <= sp.cand_cap && ctr[kSelRerun] <= n_slots)) return SW_OK;
+  std::vector<uint32_t> cand(2 * (size_t)ctr[kSelCand]), tie(2 * (size_t)ctr[kSelTie]), rr(ctr[kSelRerun]);
+  if (!cand.empty()) HIPCK(hipMemcpyAsync(cand.data(), ws.sel_cand.p, cand.size() * 4, hipMemcpyDeviceToHost, c.stream));
+  if (!tie.empty()) HIPCK(hipMemcpyAsync(tie.data(), ws.sel_tie.p, tie.size() * 4, hipMemcpyDeviceToHost, c.stream));
+  if (!rr.empty()) HIPCK(hipMemcpyAsync(rr.data(), ws.sel_rerun.p, rr.size() * 4, hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipStreamSynchronize(c.stream));
+  for (size_t i = 0; i < cand.size(); i += 2) pool.push_back(TopEntry{(int32_t)cand[i], cand[i + 1]});
+  for (size_t i = 0; i < tie.size(); i += 2) pool.push_back(TopEntry{(int32_t)tie[i], tie[i + 1]});
+  std::vector<uint32_t> rerun(db->generic);
+  for (uint32_t slot : rr) rerun.push_back(db->slot_target[slot]);
+  std::vector<int32_t> rs;
+  if ((rc = rescore_locked(c, ws, db, qp, sc, rerun, rs))) return rc;
+  for (size_t i = 0; i < rerun.size(); i++) pool.push_back(TopEntry{rs[i], rerun[i]});
+  done = true;
+  return SW_OK;
+}
+
+// the k best of `pool`, or of the full score vector when the device selection did not finish
+int finish_top_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, Scoring sc, size_t k, bool device_done,
+                      std::vector<TopEntry>& pool, std::vector<TopEntry>& top) {
+  if (!device_done) {
+    std::vector<int32_t> scores;
+    int rc = db_scores_locked(c, ws, db, qp, sc, scores);
+    if (rc) return rc;
+    pool.resize(db->n);
+    for (uint32_t i = 0; i < db->n; i++) pool[i] = TopEntry{scores[i], i};
+  }
+  const size_t kk = std::min(k, pool.size());
+  std::partial_sort(pool.begin(), pool.begin() + kk, pool.end(), top_before);
+  top.assign(pool.begin(), pool.begin() + kk);
+  return SW_OK;
+}
+
+bool device_topk(const sw_db* db, const QueryPrep& qp, Scoring sc, size_t k) {
+  return fast_path(db, qp, sc) && !g_host_topk && k <= 4096;
+}
+
 // The k best (score, target) of the database for one query.  Selection runs on the device (sw_topk.hip): only
 // the candidates and the slots that need an exact re-run are downloaded.  Falls back to the full download when
 // the tie list overflows (e.g. a database where every target scores the same) or with SW_HIP_TOPK=host.
@@ -864,70 +965,67 @@ int db_topk_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, Sc
   const uint32_t Q = (uint32_t)qp.d.sym.size();
   bool device_done = false;
   std::vector<TopEntry> pool;
-  if (fast_path(db, qp, sc) && !g_host_topk && k <= 4096) {
-    int rc = score_pass_locked(c, ws, db, qp.qwords.data(), qp.qwords.size(), (uint32_t)qp.d.sym.size(), sc);
+  if (device_topk(db, qp, sc, k)) {
+    int rc = score_pass_locked(c, ws, db, qp.qwords.data(), qp.qwords.size(), Q, sc);
     if (rc) return rc;
-    const uint32_t n_slots = (uint32_t)db->slot_target.size();
-    if ((rc = ws.sel_hist.ensure(32768 * 4))) return rc;
-    if ((rc = ws.sel_ctr.ensure(kSelWords * 4))) return rc;
-    if ((rc = ws.sel_rerun.ensure((size_t)n_slots * 4))) return rc;
-    if ((rc = ws.sel_cand.ensure(std::max<size_t>(k, 16) * 8))) return rc;
-    if ((rc = ws.sel_tie.ensure((size_t)kTieCap * 8))) return rc;
-    HIPCK(hipMemsetAsync(ws.sel_hist.p, 0, 32768 * 4, c.stream));
-    HIPCK(hipMemsetAsync(ws.sel_ctr.p, 0, kSelWords * 4, c.stream));
-    SelectParams sp{};
-    sp.slot_scores = (const int32_t*)ws.slot_scores.p;
-    sp.lens = db->d_lens;
-    sp.slot_target = db->d_slot_target;
-    sp.n_slots = n_slots;
-    sp.Q = Q;
-    sp.match = sc.match;
-    sp.k = (uint32_t)k;
-    sp.hist = (uint32_t*)ws.sel_hist.p;
-    sp.counters = (uint32_t*)ws.sel_ctr.p;
-    sp.rerun = (uint32_t*)ws.sel_rerun.p;
-    sp.rerun_cap = n_slots;
-    sp.cand = (uint32_t*)ws.sel_cand.p;
-    sp.cand_cap = (uint32_t)std::max<size_t>(k, 16);
-    sp.tie = (uint32_t*)ws.sel_tie.p;
-    sp.tie_cap = kTieCap;
-    HIPCK(launch_select(sp, c.stream));
-    uint32_t ctr[kSelWords] = {0};
-    uint32_t kerr = 0;
-    HIPCK(hipMemcpyAsync(ctr, ws.sel_ctr.p, sizeof(ctr), hipMemcpyDeviceToHost, c.stream));
-    HIPCK(hipMemcpyAsync(&kerr, (uint32_t*)ws.ticket.p + 32, 4, hipMemcpyDeviceToHost, c.stream));
-    HIPCK(hipStreamSynchronize(c.stream));
-    if ((rc = score_pass_finish_locked(c, db, Q, kerr))) return rc;
-    if (ctr[kSelTie] <= kTieCap && ctr[kSelCand] <= sp.cand_cap && ctr[kSelRerun] <= n_slots) {
-      std::vector<uint32_t> cand(2 * (size_t)ctr[kSelCand]), tie(2 * (size_t)ctr[kSelTie]), rr(ctr[kSelRerun]);
-      if (!cand.empty()) HIPCK(hipMemcpyAsync(cand.data(), ws.sel_cand.p, cand.size() * 4, hipMemcpyDeviceToHost, c.stream));
-      if (!tie.empty()) HIPCK(hipMemcpyAsync(tie.data(), ws.sel_tie.p, tie.size() * 4, hipMemcpyDeviceToHost, c.stream));
-      if (!rr.empty()) HIPCK(hipMemcpyAsync(rr.data(), ws.sel_rerun.p, rr.size() * 4, hipMemcpyDeviceToHost, c.stream));
-      HIPCK(hipStreamSynchronize(c.stream));
-      for (size_t i = 0; i < cand.size(); i += 2) pool.push_back(TopEntry{(int32_t)cand[i], cand[i + 1]});
-      for (size_t i = 0; i < tie.size(); i += 2) pool.push_back(TopEntry{(int32_t)tie[i], tie[i + 1]});
-      std::vector<uint32_t> rerun(db->generic);
-      for (uint32_t slot : rr) rerun.push_back(db->slot_target[slot]);
-      std::vector<int32_t> rs;
-      if ((rc = rescore_locked(c, ws, db, qp, sc, rerun, rs))) return rc;
-      for (size_t i = 0; i < rerun.size(); i++) pool.push_back(TopEntry{rs[i], rerun[i]});
-      device_done = true;
-    } else {
+    if ((rc = select_pool_locked(c, ws, db, qp, sc, k, (const int32_t*)ws.slot_scores.p, Q, pool, device_done))) return rc;
+    if (!device_done) {
       // undo the accounting of the pass we are about to repeat through the host path
+      pool.clear();
       c.stats.score_launches -= 1;
       c.stats.score_cells -= (uint64_t)Q * db->packed_residues;
     }
   }
-  if (!device_done) {
-    std::vector<int32_t> scores;
-    int rc = db_scores_locked(c, ws, db, qp, sc, scores);
-    if (rc) return rc;
-    pool.resize(db->n);
-    for (uint32_t i = 0; i < db->n; i++) pool[i] = TopEntry{scores[i], i};
+  return finish_top_locked(c, ws, db, qp, sc, k, device_done, pool, top);
+}
+
+// Several queries in ONE score pass (sw_score.hip, MULTI): stacked into one column of row blocks, every query on a
+// block boundary, one score array per query; then the same device selection per query.  What a short query alone
+// amortises badly -- a strip's substitution tables, the unit bookkeeping, the start of the wave pipeline -- is paid
+// once per batch.  qps[lo..hi) all pass device_topk() and agree on which targets take the full-matrix path
+// (db_topk_phase decides that).
+int db_topk_multi_locked(Context& c, Workspace& ws, sw_db* db, const std::vector<QueryPrep>& qps, size_t lo, size_t hi,
+                         Scoring sc, size_t k, std::vector<std::vector<TopEntry>>& tops) {
+  StreamDrain drain(c.stream);
+  k = std::min<size_t>(k, db->n);
+  std::vector<uint32_t> qwords, blkinfo;
+  ScoreBatch batch{};
+  for (size_t q = lo; q < hi; q++) {
+    const uint32_t Q = (uint32_t)qps[q].d.sym.size();
+    const uint32_t nb = (Q + kScoreB - 1) / kScoreB;
+    for (uint32_t b = 0; b < nb; b++) {
+      const uint32_t rows = std::min<uint32_t>(kScoreB, Q - b * kScoreB);
+      blkinfo.push_back(rows | (b == 0 ? kBlkFirst : 0u) | (b + 1 == nb ? kBlkLast : 0u) | ((uint32_t)(q - lo) << kBlkQueryShift));
+      qwords.push_back(qps[q].qwords[b]);
+    }
+    batch.rows += Q;
   }
-  const size_t kk = std::min(k, pool.size());
-  std::partial_sort(pool.begin(), pool.begin() + kk, pool.end(), top_before);
-  top.assign(pool.begin(), pool.begin() + kk);
+  qwords.push_back(0);   // the kernel fetches both one block ahead
+  blkinfo.push_back(0);
+  batch.blkinfo = blkinfo.data();
+  batch.n_blocks = (uint32_t)blkinfo.size() - 1;
+  batch.n_queries = (uint32_t)(hi - lo);
+  const uint32_t Q0 = (uint32_t)qps[lo].d.sym.size();
+  int rc = score_pass_locked(c, ws, db, qwords.data(), qwords.size(), Q0, sc, nullptr, false, &batch);
+  if (rc) return rc;
+  const size_t n_slots = db->slot_target.size();
+  std::vector<size_t> redo;
+  for (size_t q = lo; q < hi; q++) {
+    std::vector<TopEntry> pool;
+    bool done = false;
+    if ((rc = select_pool_locked(c, ws, db, qps[q], sc, k, (const int32_t*)ws.slot_scores.p + (q - lo) * n_slots,
+                                 q == lo ? batch.rows : 0, pool, done)))
+      return rc;
+    if (!done) {
+      redo.push_back(q);  // (after the loop: the host path runs a score pass of its own over the same buffers)
+      continue;
+    }
+    if ((rc = finish_top_locked(c, ws, db, qps[q], sc, k, true, pool, tops[q]))) return rc;
+  }
+  for (size_t q : redo) {
+    std::vector<TopEntry> pool;
+    if ((rc = finish_top_locked(c, ws, db, qps[q], sc, k, false, pool, tops[q]))) return rc;
+  }
   return SW_OK;
 }
 
@@ -989,9 +1087,41 @@ int swhip::db_topk_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring s
   CtxLock L(db->ctx);
   if (L.rc) return L.rc;
   reset_stats(*L.c);
-  for (size_t q = 0; q < qps.size(); q++) {
-    const int rc = db_topk_locked(*L.c, L.c->ws, db, qps[q], sc, k, tops[q]);
+  // Consecutive short queries share one score pass (db_topk_multi_locked).  They must agree on which targets take
+  // the full-matrix path (T < 2Q decides whether a target whose length is a multiple of 64 loses its last column,
+  // and that is built into a strip's tables): no such length of this database may lie in [2 Qmin, 2 Qmax).
+  // SW_HIP_QUERY_BATCH=0 switches the batching off, =n caps a batch at n queries (default 16).
+  static const size_t max_batch = [] {
+    const char* e = getenv("SW_HIP_QUERY_BATCH");
+    return e ? (size_t)std::max(0, atoi(e)) : (size_t)16;
+  }();
+  constexpr uint32_t kBatchQueryRows = 1024, kBatchRows = 4096;
+  const size_t n_slots = db->slot_target.size();
+  const size_t k_eff = std::min<size_t>(k, db->n);
+  size_t q = 0;
+  while (q < qps.size()) {
+    size_t hi = q + 1;
+    auto eligible = [&](const QueryPrep& qp) {
+      return k_eff > 0 && device_topk(db, qp, sc, k_eff) && qp.d.sym.size() <= kBatchQueryRows;
+    };
+    if (max_batch >= 2 && eligible(qps[q])) {
+      uint32_t qmin = (uint32_t)qps[q].d.sym.size(), qmax = qmin;
+      uint64_t rows = ((uint64_t)qmin + kScoreB - 1) / kScoreB * kScoreB;
+      while (hi < qps.size() && hi - q < max_batch && eligible(qps[hi])) {
+        const uint32_t Q = (uint32_t)qps[hi].d.sym.size();
+        const uint32_t lo2 = std::min(qmin, Q), hi2 = std::max(qmax, Q);
+        const uint64_t r2 = rows + ((uint64_t)Q + kScoreB - 1) / kScoreB * kScoreB;
+        const auto it = std::lower_bound(db->len64.begin(), db->len64.end(), 2 * lo2);
+        if (r2 > kBatchRows || (hi - q + 1) * n_slots * 4 > ((size_t)1 << 30) || (it != db->len64.end() && *it < 2 * (uint64_t)hi2)) break;
+        qmin = lo2, qmax = hi2, rows = r2;
+        hi++;
+      }
+    }
+    int rc;
+    if (hi - q >= 2) rc = db_topk_multi_locked(*L.c, L.c->ws, db, qps, q, hi, sc, k, tops);
+    else rc = db_topk_locked(*L.c, L.c->ws, db, qps[q], sc, k, tops[q]);
     if (rc) return rc;
+    q = hi;
   }
   return SW_OK;
 }

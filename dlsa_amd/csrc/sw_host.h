@@ -90,6 +90,7 @@ struct Workspace {
   DevBuf sel_hist, sel_ctr, sel_rerun, sel_cand, sel_tie;  // device-side top-k selection
   DevBuf qwords, slot_scores, gbound, ticket, prog, units; // score path
   DevBuf strip_best;                                       // ... per-strip maxima (work-package fast path)
+  DevBuf blkinfo;                                          // ... row blocks of a batch of queries (ScoreParams::blkinfo)
   void release();
 };
 

@@ -183,7 +183,15 @@ struct ScoreParams {
   uint32_t* err;              // set != 0 if a dependency wait timed out (zeroed before launch)
   uint32_t pub;               // blocks per publication of an inter-unit boundary column
   int match, miss, gap;
+  // A batch of queries in one pass (nullptr: one query of Q rows).  One word per row block of the stacked queries,
+  // + one padding word: bits 0..3 rows of the block (1..12), kBlkFirst / kBlkLast = first / last block of its
+  // query, bits kBlkQueryShift.. = index of the query.  qwords has one word per block accordingly; slot_scores holds
+  // one array of n_slots per query; Q is the length of any one of them (they agree on which targets take the
+  // full-matrix path, see db_topk_phase).
+  const uint32_t* blkinfo;
+  uint32_t n_blocks;
 };
+enum : uint32_t { kBlkFirst = 16u, kBlkLast = 32u, kBlkQueryShift = 8u };
 hipError_t launch_score(const ScoreParams& p, int n_workgroups, int waves, hipStream_t stream);
 int score_waves_per_group(uint32_t total_strips, int cus);  // waves per workgroup for a database of that many strips
 int score_workgroups_per_cu(int waves);

@@ -106,9 +106,11 @@ int sw_db_search_topk(sw_db *db, const char *query, struct AlignmentScores score
                       struct sw_hit *hits, int *n_hits);
 /* The same for n_queries queries in one call: what a work package of the reference holds (many queries against
  * the same targets, internal/worker/worker_impl.go:108-168 loops over its pairs).  hits has room for
- * n_queries * k records, query q's hits start at hits[q * k]; n_hits has n_queries entries.  The score pass and
- * the on-device top-k selection run per query; end cells and tracebacks of all reported hits go to the GPU in
- * one submission. */
+ * n_queries * k records, query q's hits start at hits[q * k]; n_hits has n_queries entries.  Consecutive queries
+ * of at most 1024 residues share a launch of the score kernel (up to 16 queries / 4096 rows, one score array per
+ * query; SW_HIP_QUERY_BATCH=0 switches that off, =n caps a batch at n queries); the on-device top-k selection runs
+ * per query; end cells and tracebacks of all reported hits go to the GPU in one submission.  Results do not depend
+ * on how the queries were grouped. */
 int sw_db_search_topk_batch(sw_db *db, const char *const *queries, size_t n_queries, struct AlignmentScores scores,
                             int k, struct sw_hit *hits, int *n_hits);
 /* All scores (int32, database order), for tests and for schedulers that want every pair. */

@@ -29,6 +29,24 @@ def db_case(name, qlen, lens, reps=2):
                       "gcups": round(cells / best / 1e9, 1), "stats": st, "top": hits[0]["score"] if hits else None}), flush=True)
     db.close()
 
+def db_batch_case(name, qlen, nq, lens, reps=2):
+    """nq queries of one length through sw_db_search_topk_batch (consecutive short queries share score passes)"""
+    rng = np.random.default_rng(7)
+    qs = [synth(rng, np.array([qlen]))[0].tobytes() for _ in range(nq)]
+    flat, offs = synth(rng, lens)
+    db = bridge.Database(flat=flat, offsets=offs)
+    sc = dlsa_amd.AlignmentScore(2, -1, -1)
+    best = 1e9
+    for _ in range(reps + 1):
+        t0 = time.perf_counter(); hits = db.search_topk_batch(qs, sc, 5); dt = time.perf_counter() - t0
+        best = min(best, dt)
+    st = bridge.last_stats()
+    cells = float(qlen) * float(lens.sum()) * nq
+    print(json.dumps({"case": name, "queries": nq, "cells": cells, "batch_ms": round(best * 1e3, 3), "ms_per_query": round(best * 1e3 / nq, 3),
+                      "gcups": round(cells / best / 1e9, 1), "score_launches": st["score_launches"], "score_kernel_ms": round(st["score_kernel_ms"], 3),
+                      "top": [h[0]["score"] if h else None for h in hits][:4]}), flush=True)
+    db.close()
+
 def pair_case(name, Q, T, mutate=None):
     rng = np.random.default_rng(11)
     q = synth(rng, np.array([Q]))[0]
@@ -138,6 +156,9 @@ for w in which:
 if "c3" in which: db_case("C3 (1 of 32 queries) 1kb x 1e6xU[200,5000]", 1000, rng.integers(200, 5001, size=1000000))
 if "c5" in which: db_case("C5 (1 of 1000 queries) 150 x 1e7x150", 150, np.full(10000000, 150))
 if "c5s" in which: db_case("C5 scaled 150 x 1e6x150", 150, np.full(1000000, 150))
+if "c5b" in which: db_batch_case("C5 batch: 16 x 150 nt vs 1e7 x 150", 150, 16, np.full(10000000, 150))
+if "c5sb" in which: db_batch_case("C5 scaled batch: 16 x 150 nt vs 1e6 x 150", 150, 16, np.full(1000000, 150))
+if "c3b" in which: db_batch_case("C3 batch: 8 x 1 kb vs 1e6 x U[200,5000]", 1000, 8, rng.integers(200, 5001, size=1000000))
 if "p20k" in which: pair_case("pair 20k", 20000, 20000)
 if "p50k" in which: pair_case("pair 50k", 50000, 50000)
 if "c4" in which: pair_case("C4 100k", 100000, 100000)

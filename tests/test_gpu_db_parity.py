@@ -277,3 +277,57 @@ def test_chained_units_in_every_scheduling_regime(oracle, monkeypatch):
             assert sorted(h["target_index"] for h in hits) == [7, 3000, 5999]
     finally:
         db.close()
+
+
+def test_query_batches_share_one_score_pass(oracle):
+    """Consecutive short queries of a batch run as ONE launch of the score kernel (stacked row blocks, one score array
+    per query: sw_score.hip MULTI, db_topk_phase): same hits as one search per query and as the oracle -- queries of
+    equal and of different lengths, blocks that end inside a 12-row block, units chained through HBM, targets whose
+    length is a multiple of 64 (the full-matrix quirk column depends on the query length, so such a length between
+    2 Qmin and 2 Qmax splits a batch), an int16 saturation inside a batch."""
+    import dlsa_amd
+    from dlsa_amd import bridge
+    rng = random.Random(77)
+    targets = [_rnd(rng, rng.randint(20, 700)) for _ in range(560)] + [_rnd(rng, n) for n in (64, 128, 192, 256, 320, 640) for _ in range(4)]
+    q150 = [_rnd(rng, 150) for _ in range(6)]
+    qmix = [_rnd(rng, n) for n in (100, 101, 110, 96, 12, 1)]     # [2 * 1, 2 * 110) holds 64, 128, 192: splits
+    qsplit = [_rnd(rng, 127), _rnd(rng, 130)]                     # 256 lies in [254, 260): two passes
+    for i, q in enumerate(q150):
+        targets[10 + i] = targets[10 + i][:30] + q[5:140] + targets[10 + i][30:50]
+    targets[40] = qmix[0]
+    targets[41] = qmix[2][3:] + "ACGT"
+    queries = q150 + qmix + qsplit
+    sc = (-1, 2, -1)
+    s = dlsa_amd.AlignmentScore(sc[1], sc[2], sc[0])
+    db = bridge.Database(seqs=targets)
+    try:
+        got = db.search_topk_batch(queries, s, 5)
+        launches = bridge.last_stats()["score_launches"]
+        assert launches < len(queries), launches          # batches were formed ...
+        assert launches >= 3, launches                    # ... and split where the quirk column differs
+        for q, hits in zip(queries, got):
+            assert _as_tuples(hits) == _expected_hits(oracle, q, targets, sc, 5), len(q)
+            assert _as_tuples(hits) == _as_tuples(db.search_topk(q, s, 5)), len(q)
+        # the same six queries alone: exactly one pass
+        got6 = db.search_topk_batch(q150, s, 5)
+        assert bridge.last_stats()["score_launches"] == 1
+        assert [_as_tuples(h) for h in got6] == [_as_tuples(h) for h in got[:6]]
+    finally:
+        db.close()
+    # saturation inside a batch: 900 matches of 40 pass 32767, the pair is re-run in int32
+    sc2 = (-30, 40, -30)
+    s2 = dlsa_amd.AlignmentScore(sc2[1], sc2[2], sc2[0])
+    qa, qb = _rnd(rng, 900), _rnd(rng, 900)
+    t2 = [_rnd(rng, rng.randint(100, 1200)) for _ in range(130)]
+    t2[5] = "ACG" + qa + "TT"
+    db = bridge.Database(seqs=t2)
+    try:
+        got = db.search_topk_batch([qa, qb], s2, 3)
+        assert bridge.last_stats()["score_launches"] == 1
+        exp = oracle.clean_score_plain(qa, t2[5], -30, 40, -30)   # int32 model: the i16 reference wraps here
+        assert exp == 36000 and got[0][0]["target_index"] == 5 and got[0][0]["score"] == exp and got[0][0]["length"] == 900
+        assert _as_tuples(got[1]) == _expected_hits(oracle, qb, t2, sc2, 3)
+        for q, hits in zip([qa, qb], got):
+            assert _as_tuples(hits) == _as_tuples(db.search_topk(q, s2, 3))
+    finally:
+        db.close()
