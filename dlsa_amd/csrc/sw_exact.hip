@@ -493,17 +493,20 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
         const int k0 = jm1 + (within >> LOG_RPL);
         if (k0 < wlo) break;  // window exhausted (same strip)
         if (tile_mode) {
-          // ---- a 7 x 7 TILE of cells up-left of the current one: lane (dr, dc) = (lane / 8, lane % 8) holds the code
-          // of cell (row - dr, col - dc); row 7 and column 7 of the lane grid are sentinels (never valid).  The path
-          // through the tile is followed on the scalar unit over the ballots of the two code bits -- every move
-          // adds 9 (diagonal), 8 (up) or 1 (left) to the lane index, so path order is lane order -- and the H
-          // bookkeeping of all its moves is done at once afterwards (prefix counts over the path mask).  Alignments
-          // of unrelated sequences change direction every two or three cells: this follows ~10 moves per LDS round
-          // trip where the diagonal-run iteration below follows ~3.
-          const int dr = (int)(lane >> 3), dc = (int)(lane & 7u);
+          // ---- a TILE of cells up-left of the current one, a band of 7 rows along the diagonal: lane (dr, e) =
+          // (lane / 8, lane % 8) holds the code of cell (row - dr, col - dc) with dc = dr + e - 3, i.e. e - 3 is how
+          // far the path has drifted off the diagonal (more lefts than ups); the start is lane 3.  Row 7 and the
+          // columns e = 0 and e = 7 of the lane grid are sentinels (never valid).  The path through the tile is
+          // followed on the scalar unit over the ballots of the codes -- a move adds 8 (diagonal), 7 (up) or 1 (left)
+          // to the lane index, so path order is lane order -- and the H bookkeeping of all its moves is done at once
+          // afterwards.  A path leaves the band after 7 row moves or when it drifts 3 columns off the diagonal:
+          // alignments of unrelated sequences (a gap every third move) cross it in 7.4 moves per LDS round trip
+          // (a 7 x 7 square: 7.1; strip and window edges cut some tiles short), the diagonal-run iteration below ~3.
+          const int dr = (int)(lane >> 3), e = (int)(lane & 7u);
+          const int dc = dr + e - 3;
           const int wr = within - dr, jt = jm1 - dc;
           const int kt = jt + (wr >> LOG_RPL);
-          const bool valid = dr < 7 && dc < 7 && wr >= 0 && jt >= 0 && kt >= wlo;
+          const bool valid = dr < 7 && e >= 1 && e < 7 && dc >= 0 && wr >= 0 && jt >= 0 && kt >= wlo;
           // (defaults of an invalid lane: code 0 and two symbols that differ, so the three masks below need no
           // `valid &&` -- a bool carried out of the branch costs a v_cndmask + v_cmp pair per ballot)
           uint32_t code = 0, qsym = 0x30000u, tsym = 0x40000u;
@@ -517,28 +520,30 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
           const uint64_t Dm = __builtin_amdgcn_ballot_w64(code == 3u);
           const uint64_t Um = __builtin_amdgcn_ballot_w64(code == 2u);
           const uint64_t EQ = __builtin_amdgcn_ballot_w64(qsym == tsym);
-          // The path: a move adds 8 to the lane index if the cell's code is diagonal or up, and 1 if it is diagonal
-          // or left.  At most 13 cells of a 7 x 7 tile lie on one path (dr + dc grows with every move), so the loop
-          // is unrolled with not-taken exits: 7 scalar instructions per move, no taken branch before the end.
-          const uint64_t M8 = Dm | Um, M1 = Dm | ~Um;
+          // The path: a move adds 7 to the lane index if the cell's code is diagonal or up, and 1 if it is diagonal
+          // or left.  At most 16 cells of the band lie on one path (6 row moves and at most 9 lefts keep it inside),
+          // so the loop is unrolled with not-taken exits: 7 scalar instructions per move, no taken branch before the
+          // end.
+          const uint64_t M7 = Dm | Um, M1 = Dm | ~Um;
           uint64_t PM;
           uint32_t pidx, ptmp;
 #define SW_WALK_MOVE                    \
   "s_cbranch_scc0 .Ltile_end_%=\n\t"    \
   "s_bitset1_b64 %[pm], %[idx]\n\t"     \
-  "s_bitcmp1_b64 %[m8], %[idx]\n\t"     \
-  "s_cselect_b32 %[tmp], 8, 0\n\t"      \
+  "s_bitcmp1_b64 %[m7], %[idx]\n\t"     \
+  "s_cselect_b32 %[tmp], 7, 0\n\t"      \
   "s_bitcmp1_b64 %[m1], %[idx]\n\t"     \
   "s_addc_u32 %[idx], %[idx], %[tmp]\n\t" \
   "s_bitcmp1_b64 %[v], %[idx]\n\t"
           asm volatile(
               "s_mov_b64 %[pm], 0\n\t"
-              "s_mov_b32 %[idx], 0\n\t"
-              "s_bitcmp1_b64 %[v], 0\n\t" SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE
-                  SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE
+              "s_mov_b32 %[idx], 3\n\t"
+              "s_bitcmp1_b64 %[v], 3\n\t" SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE
+                  SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE SW_WALK_MOVE
+                      SW_WALK_MOVE SW_WALK_MOVE
               ".Ltile_end_%=:"
               : [pm] "=&s"(PM), [idx] "=&s"(pidx), [tmp] "=&s"(ptmp)
-              : [v] "s"(V), [m8] "s"(M8), [m1] "s"(M1)
+              : [v] "s"(V), [m7] "s"(M7), [m1] "s"(M1)
               : "scc");
 #undef SW_WALK_MOVE
           const bool on_path = __builtin_amdgcn_inverse_ballot_w64(PM);
@@ -558,10 +563,10 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
             H -= match * cE + miss * (cD - cE) + gap * cG;
             if (on_path) gops[nops + (uint32_t)below(PM)] = (uint8_t)(isd ? 0u : (isu ? 1u : 2u));
             within -= (int)(pidx >> 3);
-            jm1 -= (int)(pidx & 7u);
+            jm1 -= (int)(pidx >> 3) + (int)(pidx & 7u) - 3;
           } else {
             // H after this lane's move (meaningful in path lanes): the moves before it by prefix counts, its own by
-            // type (scores are 16-bit and counts <= 13: 24-bit multiplies)
+            // type (scores are 16-bit and counts <= 16: 24-bit multiplies)
             const int own = isd ? (qsym == tsym ? match : miss) : gap;
             const int h_after = H - own - __mul24(miss, below(PD)) - __mul24(match - miss, below(PE)) - __mul24(gap, below(PG));
             const uint64_t stop = __builtin_amdgcn_ballot_w64(on_path && h_after <= 0);
