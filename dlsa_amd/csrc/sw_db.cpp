@@ -71,7 +71,6 @@ void db_release(sw_db* db) {
 struct DbDeleter {
   void operator()(sw_db* d) const { db_release(d); }
 };
-// The packed part of a database goes to the device (caller holds the context's lock, its device is current).
 // strips that run the half-width row loop: the last strip of a group whose targets all end within its first 8 columns
 // ... and the lengths that are multiples of 64 (per-slot lengths `lens`, 0 = padding)
 void count_half_strips(sw_db* db, const std::vector<uint32_t>& lens) {
@@ -84,6 +83,7 @@ void count_half_strips(sw_db* db, const std::vector<uint32_t>& lens) {
   db->len64.erase(std::unique(db->len64.begin(), db->len64.end()), db->len64.end());
 }
 
+// The packed part of a database goes to the device (caller holds the context's lock, its device is current).
 bool db_upload(sw_db* db, const std::vector<uint32_t>& words, const std::vector<uint32_t>& lens,
                const std::vector<uint32_t>& elem_group) {
   const size_t ngroups = db->groups.size();
@@ -105,6 +105,19 @@ bool db_upload(sw_db* db, const std::vector<uint32_t>& words, const std::vector<
   }
   return true;
 }
+// 16 residues out of {A, C, G, T} -> 2 bits each, residue r in bits [2r, 2r + 2).  ((c >> 1) ^ (c >> 2)) & 3 maps
+// 'A' 'C' 'G' 'T' to 0 1 2 3; eight bytes at a time, the 2-bit fields are then gathered by three shift-or steps.
+inline uint32_t pack8(const unsigned char* p) {
+  uint64_t x;
+  memcpy(&x, p, 8);  // (little-endian: byte r is residue r)
+  x = ((x >> 1) ^ (x >> 2)) & 0x0303030303030303ull;
+  x = (x | (x >> 6)) & 0x000f000f000f000full;
+  x = (x | (x >> 12)) & 0x000000ff000000ffull;
+  x = (x | (x >> 24)) & 0xffffull;
+  return (uint32_t)x;
+}
+inline uint32_t pack16(const unsigned char* p) { return pack8(p) | (pack8(p + 8) << 16); }
+
 // Caller holds the context's lock (its device is current).
 sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
   std::unique_ptr<sw_db, DbDeleter> holder(new sw_db);  // an exception below must not leak the device arrays
@@ -114,6 +127,7 @@ sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
   db->flat = std::move(flat);
   db->off = std::move(off);
   db->residues = db->off.back() - db->off.front();
+  StageTimer tm(db->n);
   db->packed_ok.assign(db->n, 1);
   for (uint64_t i = 0; i < db->n; i++) {
     const uint64_t len = db->off[i + 1] - db->off[i];
@@ -135,19 +149,22 @@ sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
     for (size_t i = lo; i < hi; i++) {
       const unsigned char* s = (const unsigned char*)db->flat.data() + db->off[i];
       const uint64_t len = db->off[i + 1] - db->off[i];
-      int bad = 0, nul = 0;
+      // (comparisons instead of a table look-up: the compiler turns this into 32 bytes per instruction)
+      unsigned bad = 0, nul = 0;
       for (uint64_t k = 0; k < len; k++) {
-        bad |= kCode[s[k]];  // any -1 sets the sign bit
-        nul |= (s[k] == 0);
+        const unsigned char ch = s[k];
+        bad |= !((ch == 'A') | (ch == 'C') | (ch == 'G') | (ch == 'T'));
+        nul |= (ch == 0);
       }
       if (nul) has_nul = true;
-      db->packed_ok[i] = bad >= 0;
+      db->packed_ok[i] = !bad;
     }
   });
   if (has_nul) {
     fail(SW_E_ARG, "NUL byte inside a sequence");
     return nullptr;
   }
+  tm.lap("    db: scan");
   // sequences are text like the per-pair inputs (bindings.rs:125-129): anything non-ASCII must be valid UTF-8
   for (uint64_t i = 0; i < db->n; i++) {
     if (db->packed_ok[i]) continue;
@@ -195,6 +212,7 @@ sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
   }
   db->n_elems = (uint32_t)total_strips;
   count_half_strips(db, lens);
+  tm.lap("    db: sort + groups");
   // the strip stream: strip e = dwords [e*128, e*128+128), [half][lane], 16 residues (2 bits each) per dword
   std::vector<uint32_t> words(std::max<size_t>(total_strips * kGroupTargets, 1), 0);
   std::vector<uint32_t> elem_group(std::max<size_t>(total_strips, 1), 0);
@@ -202,28 +220,33 @@ sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
     for (size_t g = glo; g < ghi; g++) {
       const ScoreGroup& G = db->groups[g];
       for (uint32_t st = 0; st < G.nstrips; st++) elem_group[G.strip_base + st] = (uint32_t)g;
-      for (int s = 0; s < kGroupTargets; s++) {
-        size_t k = g * kGroupTargets + s;
-        uint32_t ti = db->slot_target[k];
-        if (ti == UINT32_MAX) continue;
-        const unsigned char* seq = (const unsigned char*)db->flat.data() + db->off[ti];
-        const uint32_t len = lens[k];
-        uint32_t* dst = words.data() + (size_t)G.strip_base * kGroupTargets + (size_t)(s / 64) * 64 + (s % 64);
-        uint32_t col = 0;
-        for (; col + kScoreR <= len; col += kScoreR, dst += kGroupTargets) {
-          uint32_t w = 0;
-          for (int r = 0; r < kScoreR; r++) w |= (uint32_t)kCode[seq[col + r]] << (2 * r);
-          *dst = w;
-        }
-        if (col < len) {
-          uint32_t w = 0;
-          for (int r = 0; col + r < len; r++) w |= (uint32_t)kCode[seq[col + r]] << (2 * r);
-          *dst = w;
+      // in blocks of 64 strips (1024 columns): the words of a strip lie 512 bytes apart, so one target's words of a
+      // block land in a 32 KB region that stays in the cache while the other 127 targets fill it in
+      constexpr uint32_t kStripBlock = 64;
+      for (uint32_t sb = 0; sb < G.nstrips; sb += kStripBlock) {
+        const uint32_t c0 = sb * kScoreR, c1 = std::min<uint32_t>(G.nstrips, sb + kStripBlock) * kScoreR;
+        for (int s = 0; s < kGroupTargets; s++) {
+          size_t k = g * kGroupTargets + s;
+          uint32_t ti = db->slot_target[k];
+          if (ti == UINT32_MAX) continue;
+          const unsigned char* seq = (const unsigned char*)db->flat.data() + db->off[ti];
+          const uint32_t len = std::min(lens[k], c1);
+          if (len <= c0) continue;
+          uint32_t* dst = words.data() + ((size_t)G.strip_base + sb) * kGroupTargets + (size_t)(s / 64) * 64 + (s % 64);
+          uint32_t col = c0;
+          for (; col + kScoreR <= len; col += kScoreR, dst += kGroupTargets) *dst = pack16(seq + col);
+          if (col < len) {
+            uint32_t w = 0;
+            for (int r = 0; col + r < len; r++) w |= (uint32_t)kCode[seq[col + r]] << (2 * r);
+            *dst = w;
+          }
         }
       }
     }
   });
+  tm.lap("    db: pack");
   if (!db_upload(db, words, lens, elem_group)) return nullptr;
+  tm.lap("    db: upload");
   return holder.release();
 }
 
