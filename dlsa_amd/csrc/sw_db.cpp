@@ -180,9 +180,25 @@ sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
     else db->generic.push_back((uint32_t)i);
   }
   // length-sorted (descending, stable on index) groups of 128
-  std::stable_sort(packable.begin(), packable.end(), [&](uint32_t a, uint32_t b) {
-    return (db->off[a + 1] - db->off[a]) > (db->off[b + 1] - db->off[b]);
-  });
+  if ((uint64_t)db->max_len <= 8 * (uint64_t)packable.size() + 65536) {
+    // counting sort by length (10^7 reads: 0.4 s of comparison sort otherwise): positions from the longest down,
+    // filled in index order, which keeps equal lengths stable
+    std::vector<uint64_t> at((size_t)db->max_len + 2, 0);
+    for (uint32_t i : packable) at[(size_t)(db->off[i + 1] - db->off[i])]++;
+    uint64_t pos = 0;
+    for (size_t len = at.size(); len-- > 0;) {
+      const uint64_t c = at[len];
+      at[len] = pos;
+      pos += c;
+    }
+    std::vector<uint32_t> sorted(packable.size());
+    for (uint32_t i : packable) sorted[at[(size_t)(db->off[i + 1] - db->off[i])]++] = i;
+    packable.swap(sorted);
+  } else {
+    std::stable_sort(packable.begin(), packable.end(), [&](uint32_t a, uint32_t b) {
+      return (db->off[a + 1] - db->off[a]) > (db->off[b + 1] - db->off[b]);
+    });
+  }
   const size_t ngroups = (packable.size() + kGroupTargets - 1) / kGroupTargets;
   db->groups.resize(ngroups);
   db->slot_target.assign(ngroups * kGroupTargets, UINT32_MAX);
