@@ -172,6 +172,12 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
     sw_db* db = holder.db;
     st.chunks += chunks.size();
     PersistPass pp;  // (its host buffers serve every query of the set)
+    // Alignments that run on to the top of the matrix (cheap gaps: random DNA at match 2 / mismatch 1 / gap 1 is in
+    // the linear regime) leave their first window almost always.  Once half of a query's windows needed a second
+    // submission, the following queries of the set enter theirs far enough to the left right away (Q rows reach
+    // ~1.5 Q columns): one submission per query instead of two, for about the same number of cells.
+    static const bool no_wide = getenv("SW_HIP_NO_WIDE_WINDOWS") != nullptr;  // experiments
+    bool wide_first = false;
     for (uint32_t qid : set.second) {
       const Decoded& q = dec[qid];
       const uint32_t Q = (uint32_t)q.sym.size();
@@ -246,6 +252,10 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
             if (e - std::max(units[u].first_elem, G.strip_base) < kNearStrips && units[u].first_elem > G.strip_base &&
                 units[u].dep != UINT32_MAX)
               entry = units[u].dep;
+            if (wide_first)
+              for (uint32_t more = std::min<uint32_t>((Q + Q / 2) / (kScoreR * 16) + 1, 64);
+                   more > 0 && units[entry].first_elem > G.strip_base && units[entry].dep != UINT32_MAX; more--)
+                entry = units[entry].dep;
             const uint32_t first = std::max(units[entry].first_elem, G.strip_base);
             const uint32_t col0 = (first - G.strip_base) * kScoreR;
             const uint32_t cols = std::min(C.len, (st_ + 1) * kScoreR) - col0;
@@ -359,6 +369,7 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
           }
         }
         if (tm.on) fprintf(stderr, "[sw_hip]   windows: round %u: %zu windows, %zu continue\n", round_no, wins.size(), next.size());
+        if (first_round && !no_wide && 2 * next.size() >= wins.size() && wins.size() >= 8) wide_first = true;
         wins.swap(next);
         first_round = false;
         round_no++;
