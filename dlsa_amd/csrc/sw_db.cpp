@@ -40,7 +40,8 @@ struct sw_db {
   ScoreUnit* d_units = nullptr;
   uint32_t n_units = 0, units_S = 0, units_R = 0, units_W = 0;
   uint64_t units_chained = 0;        // units that hand their last H column to the next unit through HBM
-  std::vector<ScoreUnit> h_units;    // host copy of the table currently on the device
+  std::shared_ptr<const std::vector<ScoreUnit>> h_units;  // host copy of the table currently on the device (a pass
+                                                          // in flight keeps its own reference: PersistPass)
   std::vector<uint32_t> generic;  // targets scored by the exact kernel only
   uint32_t max_len = 0;
 };
@@ -676,7 +677,8 @@ struct ScoreBatch {
   uint64_t rows;            // sum of the query lengths
 };
 int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwords, size_t n_qwords, uint32_t Q,
-                      Scoring sc, HostArena* arena = nullptr, bool persist = false, const ScoreBatch* batch = nullptr) {
+                      Scoring sc, HostArena* arena = nullptr, bool persist = false, const ScoreBatch* batch = nullptr,
+                      hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr) {
   if (batch && (arena || persist || batch->n_blocks == 0 || n_qwords != (size_t)batch->n_blocks + 1))
     return fail(SW_E_ARG, "internal: bad query batch");
   const uint32_t nblk = batch ? batch->n_blocks : (Q + kScoreB - 1) / kScoreB;
@@ -710,7 +712,7 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
     if (db->units_S != S || db->units_R != ring_slots || db->units_W != W || !db->d_units) {
       std::vector<ScoreUnit> units;
       build_units(db, W, S, ring_slots, max_wg, units, &db->units_chained);
-      db->h_units = units;
+      db->h_units = std::make_shared<const std::vector<ScoreUnit>>(units);
       if (db->d_units) (void)hipFree(db->d_units);
       db->d_units = nullptr;
       if (hipMalloc(&db->d_units, std::max<size_t>(units.size(), 1) * sizeof(ScoreUnit)) != hipSuccess)
@@ -797,9 +799,10 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
   // publication lets its consumer start)
   p.pub = W == 4 ? 2 : nblk >= 400 ? 10 : 5;
   if (const char* e = getenv("SW_HIP_SCORE_PUB")) p.pub = std::max(1, atoi(e));  // experiments
-  HIPCK(hipEventRecord(c.ev0, c.stream));
+  // (the kernel's bracket: the context's pair of events, or the caller's when several passes are in flight)
+  HIPCK(hipEventRecord(ev_begin ? ev_begin : c.ev0, c.stream));
   HIPCK(launch_score(p, nwg, (int)W, c.stream));
-  HIPCK(hipEventRecord(c.ev1, c.stream));
+  HIPCK(hipEventRecord(ev_end ? ev_end : c.ev1, c.stream));
   // what this launch executes, for the roofline arithmetic of bench.py (counted, not pasted: every strip of the
   // stream walks all Q query rows through the generated row loop; a unit that hands its last column to the next
   // unit also stores those Q rows to HBM, 256 bytes each, and the consumer reads them back once)
@@ -812,7 +815,8 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
 }
 
 // after the stream has been synchronised: error word + kernel time of the last score pass
-int score_pass_finish_locked(Context& c, sw_db* db, uint64_t Q, uint32_t kerr) {  // Q: query rows of the pass (summed over a batch)
+int score_pass_finish_locked(Context& c, sw_db* db, uint64_t Q, uint32_t kerr, hipEvent_t ev_begin = nullptr,
+                             hipEvent_t ev_end = nullptr) {  // Q: query rows of the pass (summed over a batch)
   if (kerr) {
     static const char* const what[] = {"", "a wait for another workgroup's boundary column ran out of time",
                                        "a wait for a neighbouring wave ran out of time",
@@ -823,7 +827,7 @@ int score_pass_finish_locked(Context& c, sw_db* db, uint64_t Q, uint32_t kerr) {
                               std::to_string(kerr) + ")");
   }
   float ms = 0;
-  HIPCK(hipEventElapsedTime(&ms, c.ev0, c.ev1));
+  HIPCK(hipEventElapsedTime(&ms, ev_begin ? ev_begin : c.ev0, ev_end ? ev_end : c.ev1));
   c.stats.score_kernel_ms += ms;
   c.stats.score_launches += 1;
   c.stats.score_cells += Q * db->packed_residues;
@@ -1085,31 +1089,55 @@ bool swhip::prep_query(const char* query, QueryPrep& qp) {
 }
 
 // ---- a score pass whose inter-unit boundary columns stay resident (the work-package fast path, sw_package.cpp) -------
-int swhip::db_score_persist_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, Scoring sc, PersistPass& out) {
+swhip::PersistPass::~PersistPass() {
+  for (hipEvent_t e : {ev_k0, ev_k1, ev_done})
+    if (e) (void)hipEventDestroy(e);
+}
+// The pass is QUEUED (kernel, copies of its outputs into the pass's page-locked host buffers, a completion event) and
+// not waited for: the caller may queue the next query's pass on another workspace behind it and do host work.  The
+// stream must be drained before `out` goes away if db_score_persist_end_locked is not reached.
+int swhip::db_score_persist_begin_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, Scoring sc, PersistPass& out) {
   if (!fast_path(db, qp, sc)) return fail(SW_E_DOMAIN, "internal: persist pass outside the packed kernel's domain");
   const uint32_t Q = (uint32_t)qp.d.sym.size();
-  StreamDrain drain(c.stream);
-  int rc = score_pass_locked(c, ws, db, qp.qwords.data(), qp.qwords.size(), Q, sc, nullptr, true);
+  if (!out.ev_done) {
+    HIPCK(hipEventCreate(&out.ev_k0));
+    HIPCK(hipEventCreate(&out.ev_k1));
+    HIPCK(hipEventCreateWithFlags(&out.ev_done, hipEventDisableTiming));
+  }
+  int rc = score_pass_locked(c, ws, db, qp.qwords.data(), qp.qwords.size(), Q, sc, nullptr, true, nullptr, out.ev_k0, out.ev_k1);
   if (rc) return rc;
   const size_t slot_bytes = (db->slot_target.size() * 4 + 255) & ~(size_t)255, strip_bytes = (size_t)db->n_elems * 256;
   out.host.a.resize(slot_bytes + strip_bytes + 256);
   int32_t* const h_slot = (int32_t*)out.host.a.data();
   uint32_t* const h_strip = (uint32_t*)(out.host.a.data() + slot_bytes);
+  uint32_t* const h_err = (uint32_t*)(out.host.a.data() + slot_bytes + strip_bytes);
+  *h_err = 0;
   out.slot = h_slot;
   out.strip_best = h_strip;
-  uint32_t kerr = 0;
+  out.kerr = h_err;
+  out.Q = Q;
   HIPCK(hipMemcpyAsync(h_slot, ws.slot_scores.p, db->slot_target.size() * 4, hipMemcpyDeviceToHost, c.stream));
   if (strip_bytes) HIPCK(hipMemcpyAsync(h_strip, ws.strip_best.p, strip_bytes, hipMemcpyDeviceToHost, c.stream));
-  HIPCK(hipMemcpyAsync(&kerr, (uint32_t*)ws.ticket.p + 32, 4, hipMemcpyDeviceToHost, c.stream));
-  HIPCK(hipStreamSynchronize(c.stream));
-  if ((rc = score_pass_finish_locked(c, db, Q, kerr))) return rc;
-  out.units = &db->h_units;
+  HIPCK(hipMemcpyAsync(h_err, (uint32_t*)ws.ticket.p + 32, 4, hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipEventRecord(out.ev_done, c.stream));
+  out.units_keep = db->h_units;
+  out.units = out.units_keep.get();
   out.groups = &db->groups;
   out.slot_target = &db->slot_target;
   out.d_ring = (const uint32_t*)ws.gbound.p;
   out.ring_stride = (size_t)((Q + kScoreB - 1) / kScoreB) * kScoreB * 64;
   out.n_elems = db->n_elems;
   return SW_OK;
+}
+int swhip::db_score_persist_end_locked(Context& c, sw_db* db, PersistPass& out) {
+  HIPCK(hipEventSynchronize(out.ev_done));
+  return score_pass_finish_locked(c, db, out.Q, *out.kerr, out.ev_k0, out.ev_k1);
+}
+int swhip::db_score_persist_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, Scoring sc, PersistPass& out) {
+  StreamDrain drain(c.stream);
+  int rc = db_score_persist_begin_locked(c, ws, db, qp, sc, out);
+  if (rc) return rc;
+  return db_score_persist_end_locked(c, db, out);
 }
 size_t swhip::db_persist_ring_bytes(const sw_db* db, uint32_t Q, int cus) {
   const uint32_t W = (uint32_t)score_waves_per_group(db->n_elems, cus);

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -371,14 +372,25 @@ struct PersistPass {
   ArenaLease host;
   const int32_t* slot = nullptr;         // per slot: best score (32767 = saturated)
   const uint32_t* strip_best = nullptr;  // per strip 64 dwords (lo half: slot lane, hi half: slot 64 + lane)
+  std::shared_ptr<const std::vector<ScoreUnit>> units_keep;  // (a later pass may replace the database's table)
   const std::vector<ScoreUnit>* units = nullptr;   // ticket order
   const std::vector<ScoreGroup>* groups = nullptr;
   const std::vector<uint32_t>* slot_target = nullptr;
   const uint32_t* d_ring = nullptr;     // device: boundary column of ticket u at d_ring + u * ring_stride (+ lane)
   size_t ring_stride = 0;               // dwords
   uint32_t n_elems = 0;
+  // a pass in flight (db_score_persist_begin_locked .. _end_locked): its own events, its error word in `host`
+  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr, ev_done = nullptr;
+  const uint32_t* kerr = nullptr;
+  uint32_t Q = 0;
+  PersistPass() = default;
+  PersistPass(const PersistPass&) = delete;
+  PersistPass& operator=(const PersistPass&) = delete;
+  ~PersistPass();
 };
 int db_score_persist_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, Scoring sc, PersistPass& out);
+int db_score_persist_begin_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, Scoring sc, PersistPass& out);
+int db_score_persist_end_locked(Context& c, sw_db* db, PersistPass& out);
 size_t db_persist_ring_bytes(const sw_db* db, uint32_t Q, int cus);
 sw_db* db_create_on(Context* ctx, const char* flat, const uint64_t* offsets, uint64_t n);
 sw_db* db_create_owned(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off);

@@ -34,8 +34,19 @@ namespace {
 
 bool acgt_only(const Decoded& d) {
   if (!d.ascii) return false;
-  for (uint16_t s : d.sym)
-    if (s != 'A' && s != 'C' && s != 'G' && s != 'T') return false;
+  // over the source bytes (ASCII: one per symbol), a block at a time without an exit inside the block, so that the
+  // compiler makes 32 bytes per instruction of it: a package's targets are ~100 MB
+  const unsigned char* s = (const unsigned char*)d.src;
+  const size_t n = d.sym.size();
+  for (size_t i = 0; i < n; i += 4096) {
+    const size_t e = std::min(n, i + 4096);
+    unsigned bad = 0;
+    for (size_t k = i; k < e; k++) {
+      const unsigned char ch = s[k];
+      bad |= !((ch == 'A') | (ch == 'C') | (ch == 'G') | (ch == 'T'));
+    }
+    if (bad) return false;
+  }
   return true;
 }
 
@@ -80,25 +91,39 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
   const size_t n = pair_q.size();
   handled.assign(n, 0);
   g_package_stats = PackageStats{};
+  StageTimer tm0(100000);
   static const bool disabled = getenv("SW_HIP_NO_WINDOWS") != nullptr;
   if (disabled || n == 0) return SW_OK;
   if (!(sc.match > 0 && sc.miss < 0 && sc.gap < 0 && sc.match <= 16384 && sc.miss >= -16384 && sc.gap >= -16384)) return SW_OK;
   // ---- eligibility, grouped by query
-  std::vector<int8_t> acgt(dec.size(), -1);
-  auto is_acgt = [&](uint32_t d) {
-    if (acgt[d] < 0) acgt[d] = acgt_only(dec[d]) ? 1 : 0;
-    return acgt[d] == 1;
+  auto shape_ok = [&](size_t k) {
+    const uint64_t Q = dec[pair_q[k]].sym.size(), T = dec[pair_t[k]].sym.size();
+    return !(Q < 32 || T < 2048 || T < 2 * Q || T < roundup64((uint32_t)Q) || Q * (uint64_t)sc.match >= 32767 || T >= 0x7fff0000ull);
   };
+  // which sequences are pure ACGT: those of the pairs that qualify by shape, scanned once each on the host threads
+  std::vector<int8_t> acgt(dec.size(), -1);
+  size_t scan_bytes = 0;
+  for (size_t k = 0; k < n; k++) {
+    if (!shape_ok(k)) continue;
+    for (uint32_t d : {pair_q[k], pair_t[k]})
+      if (acgt[d] < 0) acgt[d] = 2, scan_bytes += dec[d].sym.size();
+  }
+  parallel_ranges(dec.size(), scan_bytes, [&](size_t lo, size_t hi) {
+    for (size_t d = lo; d < hi; d++)
+      if (acgt[d] == 2) acgt[d] = acgt_only(dec[d]) ? 1 : 0;
+  });
+  auto is_acgt = [&](uint32_t d) { return acgt[d] == 1; };
   std::map<uint32_t, std::vector<size_t>> by_query;
   double cells = 0;
   for (size_t k = 0; k < n; k++) {
     const uint64_t Q = dec[pair_q[k]].sym.size(), T = dec[pair_t[k]].sym.size();
-    if (Q < 32 || T < 2048 || T < 2 * Q || T < roundup64((uint32_t)Q) || Q * (uint64_t)sc.match >= 32767 || T >= 0x7fff0000ull) continue;
+    if (!shape_ok(k)) continue;
     if (!is_acgt(pair_q[k]) || !is_acgt(pair_t[k])) continue;
     by_query[pair_q[k]].push_back(k);
     cells += (double)Q * (double)T;
   }
   if (cells < 1e7) return SW_OK;  // a handful of small matrices: the whole-matrix path is just as fast
+  tm0.lap("  windows: eligibility");
   Context* ctx = nullptr;
   int rc = ctx_get(device, &ctx);
   if (rc) return rc;
@@ -112,8 +137,13 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
     tids.erase(std::unique(tids.begin(), tids.end()), tids.end());
     by_targets[tids].push_back(kv.first);
   }
+  tm0.lap("  windows: target sets");
   for (auto& set : by_targets) {
     const std::vector<uint32_t>& tids = set.first;
+    struct LapAtExit {  // (declared before the database holder: reports the time of its release too)
+      StageTimer& t;
+      ~LapAtExit() { t.lap("  windows: set done"); }
+    } lap_at_exit{tm0};
     // ---- chunks.  A long target is a long chain of dependent strips for the score kernel (T / 16 hops, each one
     // block of rows long): few long targets leave the GPU idle.  A target is therefore cut into overlapping CHUNKS
     // that enter the temporary database as sequences of their own.  An alignment spans at most
@@ -171,30 +201,62 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
     if (!holder.db) return SW_E_HIP;
     sw_db* db = holder.db;
     st.chunks += chunks.size();
-    PersistPass pp;  // (its host buffers serve every query of the set)
     // Alignments that run on to the top of the matrix (cheap gaps: random DNA at match 2 / mismatch 1 / gap 1 is in
     // the linear regime) leave their first window almost always.  Once half of a query's windows needed a second
     // submission, the following queries of the set enter theirs far enough to the left right away (Q rows reach
     // ~1.5 Q columns): one submission per query instead of two, for about the same number of cells.
     static const bool no_wide = getenv("SW_HIP_NO_WIDE_WINDOWS") != nullptr;  // experiments
     bool wide_first = false;
-    for (uint32_t qid : set.second) {
+    // TWO score passes in flight, on the context's two workspaces: while the host picks and submits the windows of
+    // query i (small, latency-bound submissions), the GPU already runs the pass of query i + 1, queued before them.
+    // A slot -- boundary ring, slot scores, per-strip maxima, their host copies -- is reused as soon as its query's
+    // windows are done.  The context stays locked for the whole set (both workspaces are in use).
+    struct Flight {
+      PersistPass pp;  // (its host buffers serve every other query of the set)
+      QueryPrep qp;
+      uint32_t qid = 0;
+      bool active = false;
+    };
+    Flight flights[2];
+    CtxLock L(ctx);
+    if (L.rc) return L.rc;
+    StreamDrain drain(L.c->stream);  // (declared after the flights: an early return waits for the passes in flight first)
+    size_t next_query = 0;
+    static const bool no_overlap = getenv("SW_HIP_NO_PASS_OVERLAP") != nullptr;  // experiments: one pass at a time
+    auto start = [&](int slot) -> int {
+      Flight& F = flights[slot];
+      F.active = false;
+      while (next_query < set.second.size()) {
+        const uint32_t qid = set.second[next_query++];
+        const Decoded& q = dec[qid];
+        const uint32_t Q = (uint32_t)q.sym.size();
+        if (db_persist_ring_bytes(db, Q, L.c->cus) > 2 * L.c->scratch_budget) continue;  // whole-matrix path instead
+        F.qp.d.src = q.src;
+        F.qp.d.ascii = true;
+        F.qp.d.sym = q.sym;
+        F.qp.acgt = true;
+        F.qp.qwords.assign((Q + kScoreB - 1) / kScoreB + 1, 0);
+        for (uint32_t i = 0; i < Q; i++) {
+          const uint32_t code = q.sym[i] == 'A' ? 0 : q.sym[i] == 'C' ? 1 : q.sym[i] == 'G' ? 2 : 3;
+          F.qp.qwords[i / kScoreB] |= code << (2 * (i % kScoreB));
+        }
+        const int rc2 = db_score_persist_begin_locked(*L.c, slot ? L.c->ws2 : L.c->ws, db, F.qp, sc, F.pp);
+        if (rc2) return rc2;
+        F.qid = qid;
+        F.active = true;
+        break;
+      }
+      return SW_OK;
+    };
+    if ((rc = start(0))) return rc;
+    if (!no_overlap && (rc = start(1))) return rc;
+    for (int cur = 0; flights[cur].active; cur = no_overlap ? 0 : cur ^ 1) {
+      PersistPass& pp = flights[cur].pp;
+      const uint32_t qid = flights[cur].qid;
       const Decoded& q = dec[qid];
       const uint32_t Q = (uint32_t)q.sym.size();
-      QueryPrep qp;
-      qp.d.src = q.src;
-      qp.d.ascii = true;
-      qp.d.sym = q.sym;
-      qp.qwords.assign((Q + kScoreB - 1) / kScoreB + 1, 0);
-      for (uint32_t i = 0; i < Q; i++) {
-        const uint32_t code = q.sym[i] == 'A' ? 0 : q.sym[i] == 'C' ? 1 : q.sym[i] == 'G' ? 2 : 3;
-        qp.qwords[i / kScoreB] |= code << (2 * (i % kScoreB));
-      }
       const std::vector<size_t>& pairs = by_query[qid];
-      CtxLock L(ctx);  // the boundary ring must stay as the score pass left it until this query's windows are done
-      if (L.rc) return L.rc;
-      if (db_persist_ring_bytes(db, Q, L.c->cus) > 2 * L.c->scratch_budget) continue;  // whole-matrix path instead
-      if ((rc = db_score_persist_locked(*L.c, L.c->ws, db, qp, sc, pp))) return rc;
+      if ((rc = db_score_persist_end_locked(*L.c, db, pp))) return rc;
       st.queries++;
       if (tm.on) fprintf(stderr, "[sw_hip]   windows: score kernel %.3f ms (Q = %u)\n", L.c->stats.score_kernel_ms, Q);
       tm.lap("  windows: score pass");
@@ -391,6 +453,7 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
         handled[k] = 1;
         st.pairs++;
       }
+      if ((rc = start(cur))) return rc;  // the slot is free: the next query's pass goes behind whatever is queued
     }
   }
   g_package_stats = st;
