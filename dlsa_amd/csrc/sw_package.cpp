@@ -156,15 +156,21 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
     uint32_t Qmax = 0;
     for (uint32_t qid : set.second) Qmax = std::max<uint32_t>(Qmax, (uint32_t)dec[qid].sym.size());
     const uint64_t O = (uint64_t)Qmax + (uint64_t)Qmax * (uint64_t)sc.match / (uint64_t)(-sc.gap) + 1;
-    // Chunk stride S: 2 O (half as much overlap as payload) when the set is large; a set with few residues gets
-    // shorter chunks, down to O / 2, so that it still fills the 128 lanes of a few groups -- a wave costs the same
-    // whether 21 or 128 of its lanes hold a chunk (swept on the 10 x 800 package: 1 O .. 5 O within 15 %, smaller is
-    // better because more groups mean more independent chains)
+    // Chunk stride S: 2 O (half as much overlap as payload) when the set is large; a set with fewer residues gets
+    // shorter chunks, down to O / 2, so that there are still about a hundred groups of 128 chunks -- every group is
+    // one chain of strips, and the GPU wants that many chains in flight more than it minds the extra overlap (swept:
+    // 10 x 800 targets, 8.4e7 residues: 2 O is best, 1 O +30 %, 4 O +12 %; 10 x 100 targets, 1e7 residues: 2 O 64 ms,
+    // 1 O 52 ms, O / 2 35 ms)
     uint64_t set_residues = 0;
     for (uint32_t t : tids) set_residues += dec[t].sym.size();
     static const double chunk_mult = getenv("SW_HIP_CHUNK_MULT") ? atof(getenv("SW_HIP_CHUNK_MULT")) : 2.0;  // experiments
     uint64_t S = (uint64_t)(chunk_mult * (double)O);
-    S = std::max<uint64_t>(std::min<uint64_t>(S, set_residues / 256), std::max<uint64_t>(O / 2, 1024));
+    const uint64_t S_floor = std::max<uint64_t>(O / 2, 1024);
+    const uint64_t S_many = std::max<uint64_t>(std::min<uint64_t>(S, set_residues / (100 * kGroupTargets)), S_floor);
+    // ... but only where that gets somewhere: a single pair (the capacity benchmark's 4 102 x 4.2e6) has 5 groups at
+    // O / 2 and 3 at the stride below, and loses a third of its speed to the extra overlap
+    if (set_residues / S_many >= 32 * kGroupTargets) S = S_many;
+    else S = std::max<uint64_t>(std::min<uint64_t>(S, set_residues / 256), S_floor);
     struct Chunk {
       uint32_t tid;     // index into dec
       uint32_t start;   // first target column of the chunk (0-based)
