@@ -120,7 +120,8 @@ inline uint32_t pack8(const unsigned char* p) {
 inline uint32_t pack16(const unsigned char* p) { return pack8(p) | (pack8(p + 8) << 16); }
 
 // Caller holds the context's lock (its device is current).
-sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
+// known_acgt: the caller has checked that every sequence consists of A, C, G, T only (the work-package fast path).
+sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off, bool known_acgt = false) {
   std::unique_ptr<sw_db, DbDeleter> holder(new sw_db);  // an exception below must not leak the device arrays
   sw_db* db = holder.get();
   db->ctx = ctx;
@@ -146,7 +147,7 @@ sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
     return t;
   }();
   std::atomic<bool> has_nul{false};
-  parallel_ranges(db->n, db->n >= 4096 ? db->flat.size() + ((size_t)1 << 20) : 0, [&](size_t lo, size_t hi) {
+  parallel_ranges(known_acgt ? 0 : db->n, db->n >= 4096 ? db->flat.size() + ((size_t)1 << 20) : 0, [&](size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; i++) {
       const unsigned char* s = (const unsigned char*)db->flat.data() + db->off[i];
       const uint64_t len = db->off[i + 1] - db->off[i];
@@ -1269,10 +1270,10 @@ std::string swhip::db_take_flat(sw_db* db) {
   if (db) out.swap(db->flat);
   return out;
 }
-sw_db* swhip::db_create_owned(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off) {
+sw_db* swhip::db_create_owned(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off, bool known_acgt) {
   CtxLock L(ctx);
   if (L.rc) return nullptr;
-  return db_build(L.c, std::move(flat), std::move(off));
+  return db_build(L.c, std::move(flat), std::move(off), known_acgt);
 }
 sw_db* swhip::db_open_on(Context* ctx, const char* path) {
   if (!path) {

@@ -393,7 +393,7 @@ int db_score_persist_begin_locked(Context& c, Workspace& ws, sw_db* db, const Qu
 int db_score_persist_end_locked(Context& c, sw_db* db, PersistPass& out);
 size_t db_persist_ring_bytes(const sw_db* db, uint32_t Q, int cus);
 sw_db* db_create_on(Context* ctx, const char* flat, const uint64_t* offsets, uint64_t n);
-sw_db* db_create_owned(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off);
+sw_db* db_create_owned(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off, bool known_acgt = false);
 std::string db_take_flat(sw_db* db);
 sw_db* db_open_on(Context* ctx, const char* path);  // a file written by sw_db_save
 const std::string& db_flat(const sw_db* db);

@@ -202,7 +202,7 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
     });
     tm.lap("  windows: chunks");
     DbHolder holder;
-    holder.db = db_create_owned(ctx, std::move(flat), std::move(off));
+    holder.db = db_create_owned(ctx, std::move(flat), std::move(off), true);  // (the eligibility scan above vouches for ACGT)
     tm.lap("  windows: temp db");
     if (!holder.db) return SW_E_HIP;
     sw_db* db = holder.db;
