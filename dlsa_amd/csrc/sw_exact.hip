@@ -326,6 +326,8 @@ __device__ __forceinline__ void wave_best(int& gbv, uint64_t& gkey) {
   }
 }
 
+// (211 VGPRs at 4 rows per lane = two waves per SIMD.  Forcing three or four -- amdgpu_waves_per_eu -- spills 51 / 129
+// registers and changes a batch of 1 kb pairs by -1 / -2 % and a batch of reads by +3 / +6 %: left alone.)
 template <int RPL>
 __global__ void __launch_bounds__(64) sw_exact_kernel(ExactWork W, int match, int miss, int gap) {
   const int lane = threadIdx.x;
