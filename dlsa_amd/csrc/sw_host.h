@@ -327,7 +327,12 @@ void parallel_ranges(size_t n, size_t work, F&& f) {
 struct StageTimer {
   bool on;
   std::chrono::steady_clock::time_point t0;
-  explicit StageTimer(size_t n) : on(n >= 1000 && getenv("SW_HIP_TRACE")), t0(std::chrono::steady_clock::now()) {}
+  // (submissions of at least 1000 pairs, or SW_HIP_TRACE_MIN)
+  static size_t min_pairs() {
+    static const size_t v = getenv("SW_HIP_TRACE_MIN") ? (size_t)atoll(getenv("SW_HIP_TRACE_MIN")) : 1000;
+    return v;
+  }
+  explicit StageTimer(size_t n) : on(n >= min_pairs() && getenv("SW_HIP_TRACE")), t0(std::chrono::steady_clock::now()) {}
   void lap(const char* what) {
     if (!on) return;
     const auto t1 = std::chrono::steady_clock::now();
