@@ -140,6 +140,12 @@ def main():
     if args.queries:
         wl["n_queries"] = args.queries
 
+    # Libraries print to stdout (RCCL's version banner at init): keep file descriptor 1 for the ONE JSON line and
+    # send everything else to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,7 +156,15 @@ def main():
     rehearsal = os.environ.get("SW_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
-    if world > 1:
+    # SW_BENCH_FORCE_DIST=1: take the N > 1 branch (process group on RCCL, sharder, device-tensor all_gather, all_reduce)
+    # even with ONE rank, so that every line of it has run on the hardware a one-GPU box offers.
+    force_dist = os.environ.get("SW_BENCH_FORCE_DIST") == "1"
+    if force_dist and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if rehearsal:
@@ -178,7 +192,7 @@ def main():
         lens = bridge.synth_lengths(SEED + 1, n_global, wl["t_min"], wl["t_max"])
     g_off = np.zeros(n_global + 1, dtype=np.uint64)
     g_off[1:] = np.cumsum(lens, dtype=np.uint64)
-    if world > 1:
+    if world > 1 or force_dist:
         mine = shard.local_targets(shard.plan(g_off, world), rank)
     else:
         mine = np.arange(n_global, dtype=np.int64)
@@ -207,7 +221,7 @@ def main():
         else:
             hits = db.search_topk_batch(queries, score, TOP_K)
             st = bridge.last_stats()
-        merged = shard.merge_topk_batch(hits, TOP_K, mine, dist, dev)
+        merged = shard.merge_topk_batch(hits, TOP_K, mine, dist, dev, always=force_dist)
         return merged, st
 
     for _ in range(args.warmup):
@@ -263,7 +277,9 @@ def main():
                        "cells_per_step": step_cells,
                        "parallelism": (f"one process, {args.node_shards} logical shard(s) via sw_node_*" if ndb is not None else
                                        f"one database sharded by target over {world} GPU(s) (sw_shard_plan), "
-                                       f"one all_gather of {wl['n_queries']} x {TOP_K} records")},
+                                       f"one all_gather of {wl['n_queries']} x {TOP_K} records"
+                                       + (" (SW_BENCH_FORCE_DIST: the collective path taken with one rank)" if force_dist and world == 1 else ""))},
+            "backend": (dist.get_backend() if dist is not None else None),
             # value_cold: the same step including the one-time sw_db_create of the shard (validation, length sort,
             # 2-bit packing on host threads, upload); never `value`
             "value_cold": step_cells / (db_build_s + elapsed / args.steps) / 1e9, "db_build_s": db_build_s,
@@ -286,7 +302,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             out["cpu_baseline"] = cpu_baseline(bridge, queries[0], flat, offsets, len(mine))
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     for h in (db, ndb, node):
         if h is not None:
             h.close()

@@ -28,9 +28,10 @@ def local_targets(shard_of, rank):
     return np.flatnonzero(np.asarray(shard_of) == rank).astype(np.int64)
 
 
-def merge_topk_batch(local_hits, k, global_index, dist=None, device="cpu"):
+def merge_topk_batch(local_hits, k, global_index, dist=None, device="cpu", always=False):
     """local_hits[q]: this rank's own top-k for query q (dicts with score / target_index (shard-local) / max_x /
-    max_y).  Returns, per query, the global top-k as [score, global_index, max_x, max_y] rows.  One collective."""
+    max_y).  Returns, per query, the global top-k as [score, global_index, max_x, max_y] rows.  One collective
+    (skipped for a single rank unless `always`)."""
     nq = len(local_hits)
     rec = torch.full((max(nq, 1), k, 4), -1, dtype=torch.int64)
     for q, hits in enumerate(local_hits):
@@ -41,7 +42,7 @@ def merge_topk_batch(local_hits, k, global_index, dist=None, device="cpu"):
             rec[q, i, 1] = int(global_index[h["target_index"]])
             rec[q, i, 2] = _as_i64(h["max_x"])
             rec[q, i, 3] = _as_i64(h["max_y"])
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized() and (dist.get_world_size() > 1 or always):
         rec = rec.to(device)
         world = dist.get_world_size()
         allrec = torch.empty((world * rec.shape[0], k, 4), dtype=rec.dtype, device=rec.device)  # rank-major concat
