@@ -60,7 +60,9 @@ class CStats(C.Structure):  # include/sw_hip.h struct sw_kernel_stats
                 ("exact_cells", C.c_uint64), ("score_launches", C.c_uint32), ("rerun_pairs", C.c_uint32),
                 ("score_strip_rows", C.c_uint64), ("score_chain_rows", C.c_uint64),
                 ("score_packed_per_row", C.c_uint32), ("score_aux_per_2rows", C.c_uint32),
-                ("score_workgroups", C.c_uint32), ("pad_", C.c_uint32)]
+                ("score_workgroups", C.c_uint32), ("pad_", C.c_uint32),
+                ("lanes_kernel_ms", C.c_double), ("lanes_cells", C.c_uint64), ("lanes_padded_cells", C.c_uint64),
+                ("lanes_pairs", C.c_uint64)]
 
 
 @dataclass

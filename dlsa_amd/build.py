@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsw_hip.so")
-SOURCES = ["sw_exact.hip", "sw_score.hip", "sw_topk.hip", "sw_lib.cpp", "sw_db.cpp", "sw_node.cpp", "sw_package.cpp", "sw_worker.cpp"]
+SOURCES = ["sw_exact.hip", "sw_lanes.hip", "sw_score.hip", "sw_topk.hip", "sw_lib.cpp", "sw_lanes.cpp", "sw_db.cpp", "sw_node.cpp", "sw_package.cpp", "sw_worker.cpp"]
 HEADERS = [os.path.join(CSRC, "sw_internal.h"), os.path.join(CSRC, "sw_host.h"), os.path.join(CSRC, "sw_score_asm.inc"), os.path.join(CSRC, "gen_score_asm.py"), os.path.join(HERE, "..", "include", "sw.h"),
            os.path.join(HERE, "..", "include", "sw_hip.h"), os.path.join(HERE, "..", "include", "sw_worker.h")]
 

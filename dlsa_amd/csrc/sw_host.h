@@ -292,6 +292,12 @@ int run_exact(Context& c, Workspace& ws, const PairSpec* specs, size_t n, Scorin
 int align_windows(const std::vector<Decoded>& dec, const std::vector<uint32_t>& pair_q, const std::vector<uint32_t>& pair_t,
                   Scoring sc, std::vector<PairOut>& po, OpsArena& arena, std::vector<uint8_t>& handled,
                   int device = -1);
+// The one-pair-per-lane exact kernel (sw_lanes.cpp / sw_lanes.hip) for big batches of short pairs: answers the pairs
+// it is eligible for and that its cost model prefers (po[k], ops appended to `arena`, handled[k] = 1), leaves the
+// rest alone.  small_syms[k]: every symbol of both sequences is below 0xfffe (the kernel's sentinels).  Takes the
+// lock of `device`'s context itself.
+int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* small_syms, Scoring sc, PairOut* po,
+                OpsArena& arena, uint8_t* handled);
 // A batch of pairs on one device (sw_lib.cpp): the body of sw_align_batch.  out[i] = NULL for a pair the reference
 // would have failed on; a non-zero return means nothing was handed over.
 int align_many_on(int device, const char* const* queries, const char* const* targets, size_t n, AlignmentScores as,

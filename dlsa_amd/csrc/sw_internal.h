@@ -131,6 +131,37 @@ hipError_t launch_exact(const ExactWork& w, Scoring sc, hipStream_t stream);
 hipError_t launch_walk(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, int rpl, Scoring sc,
                        hipStream_t stream);
 
+// ---- exact kernel for big batches of short pairs: one pair per lane (sw_lanes.hip) ---------------------------
+struct LanePair {       // lane l of group g: lanes[g * 64 + l]
+  uint32_t qoff, toff;  // first symbol in the pool (u16 units, multiples of 8: the kernel loads 16 bytes at a time)
+  uint32_t Q, T;        // rows; columns computed (Tlim of the path).  Q == 0: idle lane
+  uint32_t pair;        // output slot
+  uint32_t pad_;
+  uint64_t ops_off;     // traceback ops of this pair in LanesWork::ops (capacity Q + T)
+};
+struct LaneGroup {      // 64 pairs, one wave
+  uint32_t Qmax;        // rows the wave runs: max Q of its lanes, rounded up to 8
+  uint32_t nstrips;     // 16-column strips: ceil(max T / 16)
+  uint64_t dirs_off;    // dwords: direction words of the group, [strip][row][lane]
+  uint64_t hb_off;      // dwords: boundary column between strips, [row][lane], rewritten in place by every strip
+};
+struct LaneOut {
+  int32_t score;        // H of the best cell (0: no hit)
+  uint32_t bx, bj;      // best cell, 1-based (0: none)
+  uint32_t nops;        // traceback ops written by the walker
+};
+struct LanesWork {
+  const LaneGroup* groups;
+  const LanePair* lanes;
+  const uint16_t* pool;  // symbols; padded so that 32-byte loads at any sequence start + multiple of 16 stay inside
+  uint32_t* dirs;
+  uint32_t* hb;
+  uint8_t* ops;
+  LaneOut* outs;
+  uint32_t n_groups;
+};
+hipError_t launch_lanes(const LanesWork& w, Scoring sc, bool want_trace, hipStream_t stream);
+
 // ---- inter-task score kernel ---------------------------------------------------------------------------
 constexpr int kScoreR = 16;       // target columns per wave (one 2-bit packed dword per target)
 #ifndef SW_SCORE_B

@@ -1,0 +1,235 @@
+// dlsa_amd/csrc/sw_lanes.cpp -- host side of the one-pair-per-lane exact kernel (sw_lanes.hip): which pairs of a
+// batch it may answer, whether that pays, the length-sorted groups of 64, one submission per slice of groups.
+//
+// Caller: align_interned (sw_lib.cpp), i.e. sw_align_batch / sw_execute_work / the combined per-pair callers -- the
+// record-per-pair protocol of internal/worker/worker_impl.go:108-168.  Results are those of the whole-matrix path
+// (sw_exact.hip) bit for bit: same score, same first maximal cell in the reference's discovery order, same
+// traceback (tests/test_gpu_lanes.py compares both with the oracle).
+#include <algorithm>
+#include <cstring>
+#include <unordered_map>
+
+#include "sw_host.h"
+
+namespace swhip {
+
+namespace {
+
+// SW_HIP_LANES: "0" never, "1" whenever a pair is eligible (tests), unset / "auto": when the cost model says so
+// (read at every call, so that a test can switch it)
+int lanes_mode() {
+  const char* e = getenv("SW_HIP_LANES");
+  if (!e || !*e || !strcmp(e, "auto")) return 2;
+  return atoi(e) ? 1 : 0;
+}
+
+struct Elig {
+  uint32_t k;     // index into specs
+  uint32_t Q, T;  // rows, columns computed (Tlim)
+  bool row1_extra;  // the path also computes H(1, Tlim + 1) (T % 64 == 0 quirk): decided after the kernel
+};
+
+}  // namespace
+
+int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* small_syms, Scoring sc, PairOut* po,
+                OpsArena& arena, uint8_t* handled) {
+  const int mode = lanes_mode();
+  if (mode == 0 || n == 0) return SW_OK;
+  // the kernel's domain: sentinel cells lose only if every step off a match costs something
+  if (!(sc.match > 0 && sc.miss < 0 && sc.gap < 0)) return SW_OK;
+  StageTimer tm(n);
+  std::vector<Elig> el;
+  el.reserve(n);
+  for (size_t k = 0; k < n; k++) {
+    if (handled[k] || !small_syms[k]) continue;
+    const PairSpec& s = specs[k];
+    if (s.path == SW_PATH_STRAIGHT || s.left || s.col0 || s.Tfull || s.Qfull || s.walk_x) continue;
+    if (s.Q == 0 || s.T == 0 || (uint64_t)s.Q + s.T > 65000u) continue;
+    const PathParams pp = resolve_path(s.path, s.Q, s.T);
+    if (pp.phaseQp || pp.straight || pp.Tlim == 0 || pp.T0 < pp.Tlim) continue;
+    // V = H << 16 | tag must stay a non-negative int32
+    if ((uint64_t)std::min(s.Q, pp.Tlim) * (uint64_t)sc.match > 32767u) continue;
+    el.push_back(Elig{(uint32_t)k, s.Q, pp.Tlim, pp.T0 > pp.Tlim});
+  }
+  if (el.empty()) return SW_OK;
+  // length-sorted (rows, then columns, descending): the lanes of a wave run max rows x max strips of their group
+  const bool sorted = std::is_sorted(el.begin(), el.end(), [](const Elig& a, const Elig& b) {
+    return a.Q != b.Q ? a.Q > b.Q : a.T > b.T;
+  });
+  if (!sorted)
+    std::stable_sort(el.begin(), el.end(), [](const Elig& a, const Elig& b) { return a.Q != b.Q ? a.Q > b.Q : a.T > b.T; });
+  const size_t n_groups = (el.size() + 63) / 64;
+  std::vector<LaneGroup> groups(n_groups);
+  double cyc_sum = 0, cyc_max = 0, wave_ns = 0;
+  uint64_t padded_cells = 0;
+  for (size_t g = 0; g < n_groups; g++) {
+    const size_t lo = g * 64, hi = std::min(el.size(), lo + 64);
+    uint32_t qmax = 0, tmax = 0;
+    for (size_t i = lo; i < hi; i++) {
+      qmax = std::max(qmax, el[i].Q);
+      tmax = std::max(tmax, el[i].T);
+      // what the row-strip wavefront kernel needs for the pair (measured: reads 0.48 TCUPS, 1 kb pairs 1.85)
+      const double strips = (el[i].Q + 255) / 256;
+      wave_ns += strips * 256.0 * (el[i].T + 63.0) / (el[i].Q < 256 ? 1.2e3 : 2.0e3);
+    }
+    groups[g].Qmax = (qmax + 7) / 8 * 8;
+    groups[g].nstrips = (tmax + 15) / 16;
+    const double cyc = (double)groups[g].Qmax * groups[g].nstrips * 16 * 30.0;  // issue cycles of one wave
+    cyc_sum += cyc;
+    cyc_max = std::max(cyc_max, cyc);
+    padded_cells += (uint64_t)groups[g].Qmax * groups[g].nstrips * 16 * 64;
+  }
+  if (mode == 2) {
+    // a wave alone on its SIMD issues at about half rate; 1024 SIMDs share the sum
+    const double lanes_ns = std::max(cyc_max / 0.5, cyc_sum / 1024 / 0.75) / 2.4;
+    if (el.size() < 4096 || lanes_ns > 0.8 * wave_ns) return SW_OK;
+  }
+  tm.lap("lanes: eligible + sort");
+
+  CtxLock L(device);
+  if (L.rc) return L.rc;
+  Context& c = *L.c;
+  Workspace& ws = c.ws;
+  int erc = SW_OK;
+  for (hipEvent_t* e : {&ws.ev_k0, &ws.ev_k1, &ws.ev_done})
+    if (!*e && hipEventCreate(e) != hipSuccess) return fail(SW_E_HIP, "hipEventCreate");
+
+  // slices of groups that fit the scratch budget (direction words dominate: rows x strips x 256 bytes per group)
+  size_t g0 = 0;
+  while (g0 < n_groups) {
+    size_t g1 = g0, dir_words = 0, hb_words = 0, ops_bytes = 0;
+    while (g1 < n_groups) {
+      const size_t dw = (size_t)groups[g1].Qmax * groups[g1].nstrips * 64, hw = (size_t)groups[g1].Qmax * 64;
+      if (g1 > g0 && (dir_words + dw + hb_words + hw) * 4 > c.scratch_budget) break;
+      groups[g1].dirs_off = dir_words;
+      groups[g1].hb_off = hb_words;
+      dir_words += dw;
+      hb_words += hw;
+      g1++;
+    }
+    const size_t p0 = g0 * 64, p1 = std::min(el.size(), g1 * 64), np = p1 - p0, ng = g1 - g0;
+    // symbol pool of the slice: every distinct sequence once, 16-byte aligned
+    std::unordered_map<const uint16_t*, uint32_t> seen;
+    std::vector<uint32_t> by_id;
+    struct SeqCopy {
+      const uint16_t* p;
+      uint32_t len, off;
+    };
+    std::vector<SeqCopy> copies;
+    size_t pool_syms = 0;
+    auto add_seq = [&](const uint16_t* p, uint32_t len, uint32_t id) -> uint32_t {
+      if (id != UINT32_MAX) {
+        if (id >= by_id.size()) by_id.resize((size_t)id + 1 + by_id.size() / 2, UINT32_MAX);
+        if (by_id[id] != UINT32_MAX && copies[by_id[id]].p == p && copies[by_id[id]].len == len) return copies[by_id[id]].off;
+      } else {
+        auto it = seen.find(p);
+        if (it != seen.end() && copies[it->second].len == len) return copies[it->second].off;
+      }
+      const uint32_t off = (uint32_t)pool_syms;
+      copies.push_back(SeqCopy{p, len, off});
+      pool_syms += ((size_t)len + 7) & ~(size_t)7;
+      if (id != UINT32_MAX) by_id[id] = (uint32_t)copies.size() - 1;
+      else seen[p] = (uint32_t)copies.size() - 1;
+      return off;
+    };
+    auto align64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
+    std::vector<LanePair> lanes(ng * 64);
+    memset(lanes.data(), 0, lanes.size() * sizeof(LanePair));
+    uint64_t cells = 0;
+    for (size_t i = p0; i < p1; i++) {
+      const PairSpec& s = specs[el[i].k];
+      LanePair& lp = lanes[i - p0];
+      lp.qoff = add_seq(s.q, s.Q, s.qid);
+      lp.toff = add_seq(s.t, s.T, s.tid);
+      if (pool_syms > 0x7fffff00u) return fail(SW_E_ARG, "too many symbols in one submission");
+      lp.Q = el[i].Q;
+      lp.T = el[i].T;
+      lp.pair = (uint32_t)(i - p0);
+      lp.ops_off = ops_bytes;
+      ops_bytes += ((size_t)s.Q + s.T + 15) & ~(size_t)15;
+      cells += (uint64_t)s.Q * s.T;
+    }
+    pool_syms += 64;  // (the kernel loads 32 bytes at a sequence's last 16-symbol boundary)
+    const size_t in_groups = 0, in_lanes = align64(ng * sizeof(LaneGroup)), in_pool = in_lanes + align64(lanes.size() * sizeof(LanePair));
+    const size_t in_bytes = in_pool + align64(pool_syms * 2);
+    const size_t out_ops = align64(np * sizeof(LaneOut)), out_bytes = out_ops + align64(ops_bytes);
+    if ((erc = ws.xin.ensure(in_bytes))) return erc;
+    if ((erc = ws.h_in.ensure(in_bytes))) return erc;
+    if ((erc = ws.dirs.ensure(std::max<size_t>(dir_words * 4, 16)))) return erc;
+    if ((erc = ws.xzero.ensure(std::max<size_t>(hb_words * 4, 16)))) return erc;
+    if ((erc = ws.xout.ensure(out_bytes))) return erc;
+    if ((erc = ws.h_out.ensure(out_ops))) return erc;
+    uint8_t* const h_in = (uint8_t*)ws.h_in.p;
+    for (size_t g = g0; g < g1; g++) {
+      LaneGroup gg = groups[g];
+      memcpy(h_in + in_groups + (g - g0) * sizeof(LaneGroup), &gg, sizeof(LaneGroup));
+    }
+    memcpy(h_in + in_lanes, lanes.data(), lanes.size() * sizeof(LanePair));
+    uint16_t* const hpool = (uint16_t*)(h_in + in_pool);
+    parallel_ranges(copies.size(), pool_syms * 2, [&](size_t lo, size_t hi) {
+      for (size_t k = lo; k < hi; k++) {
+        memcpy(hpool + copies[k].off, copies[k].p, (size_t)copies[k].len * 2);
+        const size_t pad = (((size_t)copies[k].len + 7) & ~(size_t)7) - copies[k].len;
+        if (pad) memset(hpool + copies[k].off + copies[k].len, 0xff, pad * 2);
+      }
+    });
+    memset(hpool + pool_syms - 64, 0xff, 128);
+    tm.lap("lanes: stage");
+    StreamDrain drain(c.stream);
+    HIPCK(hipMemcpyAsync(ws.xin.p, h_in, in_bytes, hipMemcpyHostToDevice, c.stream));
+    HIPCK(hipEventRecord(ws.ev_k0, c.stream));
+    LanesWork w{};
+    w.groups = (const LaneGroup*)((uint8_t*)ws.xin.p + in_groups);
+    w.lanes = (const LanePair*)((uint8_t*)ws.xin.p + in_lanes);
+    w.pool = (const uint16_t*)((uint8_t*)ws.xin.p + in_pool);
+    w.dirs = (uint32_t*)ws.dirs.p;
+    w.hb = (uint32_t*)ws.xzero.p;
+    w.ops = (uint8_t*)ws.xout.p + out_ops;
+    w.outs = (LaneOut*)ws.xout.p;
+    w.n_groups = (uint32_t)ng;
+    HIPCK(launch_lanes(w, sc, true, c.stream));
+    HIPCK(hipEventRecord(ws.ev_k1, c.stream));
+    HIPCK(hipMemcpyAsync(ws.h_out.p, ws.xout.p, np * sizeof(LaneOut), hipMemcpyDeviceToHost, c.stream));
+    const size_t arena_base = arena.size();
+    arena.resize(arena_base + ops_bytes);  // (page-locked: the copy lands in place)
+    if (ops_bytes)
+      HIPCK(hipMemcpyAsync(arena.data() + arena_base, (uint8_t*)ws.xout.p + out_ops, ops_bytes, hipMemcpyDeviceToHost, c.stream));
+    HIPCK(hipStreamSynchronize(c.stream));
+    drain.dismiss();
+    float ms = 0;
+    HIPCK(hipEventElapsedTime(&ms, ws.ev_k0, ws.ev_k1));
+    c.stats.exact_kernel_ms += ms;
+    c.stats.lanes_kernel_ms += ms;
+    tm.lap("lanes: gpu");
+    const LaneOut* ho = (const LaneOut*)ws.h_out.p;
+    uint64_t answered = 0;
+    for (size_t i = p0; i < p1; i++) {
+      const LaneOut& o = ho[i - p0];
+      // The path also computes H(1, Tlim + 1) <= match, a cell this kernel leaves out: it can only be the best
+      // cell if nothing scored above match.  Such a pair goes to the whole-matrix path.
+      if (el[i].row1_extra && o.score <= sc.match) continue;
+      PairOut& r = po[el[i].k];
+      r = PairOut{};
+      r.score = o.score;
+      r.bx = o.bx;
+      r.bj = o.bj;
+      r.nops = o.nops;
+      r.ops_off = arena_base + lanes[i - p0].ops_off;
+      r.end_x = r.end_j = 0;
+      r.end_H = 0;
+      r.key = o.score > 0 ? (((uint64_t)(o.bx + o.bj) << 31) | o.bx) : ~0ull;
+      handled[el[i].k] = 1;
+      answered++;
+    }
+    c.stats.exact_cells += cells;
+    c.stats.lanes_cells += cells;
+    c.stats.lanes_pairs += answered;
+    for (size_t g = g0; g < g1; g++) c.stats.lanes_padded_cells += (uint64_t)groups[g].Qmax * groups[g].nstrips * 16 * 64;
+    tm.lap("lanes: results");
+    g0 = g1;
+  }
+  (void)padded_cells;
+  return SW_OK;
+}
+
+}  // namespace swhip

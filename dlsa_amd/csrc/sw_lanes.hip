@@ -1,0 +1,227 @@
+// dlsa_amd/csrc/sw_lanes.hip -- exact Smith-Waterman for BIG BATCHES of short pairs on gfx950: one pair per LANE.
+//
+// What it replaces: the same reference functions as sw_exact.hip (matrix fill rust/src/algorithm/mod.rs:66-202 /
+// :204-445, best cell rust/src/lib.rs:122-135, traceback algorithm/mod.rs:637-714), for the record-per-pair
+// protocol of the worker (internal/worker/worker_impl.go:108-168) when a work package holds tens of thousands of
+// pairs of reads: there the row-strip wavefront of sw_exact.hip wastes lanes (a 150-row read fills 38 of 64) and
+// steps (the 64-step skew), and needs a DPP shift, a hand-over and a compare + select per cell.
+//
+// Formulation (inter-task, like the score kernel, but exact and with a traceback): a wave holds 64 PAIRS, one per
+// lane, length-sorted by the host so that the lanes of a wave finish together.  A lane keeps a strip of 16 target
+// columns of its own matrix in registers and walks down its query; the strip's right-hand H column goes to the next
+// strip through one dword per row in HBM ([row][lane], coalesced, in place).  No lane ever talks to another lane:
+// no DPP, no skew, no flags, no polling, nothing that could wait.
+//
+// Arithmetic (int32, exact on the domain the host admits: min(Q, T) x match <= 32767, Q + T < 65535): a value is
+//   V = H << 16 | tag.  The three candidates of a cell carry tag 3 (diagonal), 2 (up), 1 (left) in their low bits,
+// so ONE v_max3_i32 yields the new H and, in its low bits, which candidate won with the reference's priority among
+// equal values (diagonal, then up, then left: algorithm/mod.rs:665-706); the saturating subtract that applies the
+// gap is also the recurrence's max(., 0).  The two direction bits enter the row's direction word with one
+// v_alignbit_b32 (16 columns x 2 bits = exactly one dword per row and strip).  The low half of a cleaned value is
+// free, so the first maximal cell of every COLUMN is kept with one OR and one unsigned max: the key
+// H << 16 | (0xffff - row) is largest for the largest H and, among equal H, the smallest row.  Of the cells that
+// reach the pair's maximum the reference takes the one with the smallest x + j, then the smallest x (first flat
+// index of the skewed matrix, lib.rs:122; ring path: strict row maxima in row order, mod.rs:358-362); within a
+// column that is the smallest row, so the column records are enough and the strip's 16 records are folded into the
+// lane's best (value, x + j, x) once per strip.
+// Instruction mix per cell (profiles/r03_valu_issue.txt: add / sub / and / or / xor issue at 2 cycles per wave,
+// max / cmp / cndmask / alignbit / every packed op at 4): v_cmp + v_cndmask + v_add (diag + s), two v_sub_u32 clamp,
+// v_max3_i32, v_alignbit, v_and, v_or, v_max_u32 = 10 instructions, 30 issue cycles -- against 12 instructions / 38
+// cycles plus per-step overhead in the wavefront kernel, with every lane busy.
+//
+// Cells outside a lane's matrix (rows >= Q, columns >= T of a wave whose other lanes are longer) are computed with
+// sentinel symbols that never match; with miss < 0 and gap < 0 such a cell is strictly smaller than some real cell
+// (or 0), so it never wins the maximum, and the walker never visits it.
+#include "sw_internal.h"
+
+namespace swhip {
+
+namespace {
+
+constexpr uint32_t kSentQ = 0xffffu, kSentT = 0xfffeu;  // (the host admits only symbols below 0xfffe)
+
+template <class T>
+using gptr = __attribute__((address_space(1))) T*;
+
+__device__ __forceinline__ uint32_t sat_sub(uint32_t a, uint32_t b) { return __builtin_elementwise_sub_sat(a, b); }
+
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+// symbol i (0..7) of eight u16 held in four dwords
+__device__ __forceinline__ uint32_t sym8(const u4& w, int i) {
+  const uint32_t d = i < 2 ? w.x : (i < 4 ? w.y : (i < 6 ? w.z : w.w));
+  return (i & 1) ? (d >> 16) : (d & 0xffffu);
+}
+
+struct CellK {
+  int scM, scX;          // (match << 16) | 3, (miss << 16) | 3
+  uint32_t lsub, usub;   // (-gap << 16) - 1, (-gap << 16) - 2
+};
+
+// One row of the strip: 16 cells, left to right.  hl = H(r, first column - 1), hd = H(r - 1, first column - 1).
+__device__ __forceinline__ void lane_row(uint32_t q, const uint32_t (&t)[16], uint32_t (&H)[16], uint32_t (&colkey)[16],
+                                         uint32_t hl, uint32_t hd, uint32_t stamp, const CellK& K, uint32_t& acc,
+                                         uint32_t& hright) {
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const uint32_t hu = H[c];
+    const int sc = (q == t[c]) ? K.scM : K.scX;
+    const int d = (int)hd + sc;
+    const int lf = (int)sat_sub(hl, K.lsub);
+    const int up = (int)sat_sub(hu, K.usub);
+    const int ht = max(max(d, lf), up);
+    acc = __builtin_amdgcn_alignbit((uint32_t)ht, acc, 2);  // column c ends up in bits [2c, 2c + 2)
+    const uint32_t hn = (uint32_t)ht & 0xffff0000u;
+    colkey[c] = max(colkey[c], hn | stamp);
+    hd = hu;
+    hl = hn;
+    H[c] = hn;
+  }
+  hright = hl;
+}
+
+}  // namespace
+
+// One wave per group of 64 pairs.
+__global__ void __launch_bounds__(64) sw_lanes_kernel(LanesWork W, int match, int miss, int gap) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t g = blockIdx.x;
+  if (g >= W.n_groups) return;
+  const LaneGroup G = W.groups[g];
+  const LanePair P = W.lanes[(size_t)g * 64 + lane];
+  const gptr<const uint16_t> pool = (gptr<const uint16_t>)W.pool;
+  const gptr<uint32_t> dirs = (gptr<uint32_t>)W.dirs + G.dirs_off + lane;
+  const gptr<uint32_t> hb = (gptr<uint32_t>)W.hb + G.hb_off + lane;
+  const uint32_t Q = P.Q, T = P.T;  // 0: idle lane (every symbol a sentinel)
+  CellK K;
+  K.scM = (int)(((uint32_t)match << 16) | 3u);
+  K.scX = (int)(((uint32_t)miss << 16) | 3u);
+  K.lsub = ((uint32_t)(-gap) << 16) - 1u;
+  K.usub = ((uint32_t)(-gap) << 16) - 2u;
+  const uint32_t nblk = G.Qmax / 8;  // (Qmax is a multiple of 8)
+
+  uint32_t bestH = 0, bestkey = 0xffffffffu;  // key = (x + j) << 16 | x, 1-based
+  for (uint32_t s = 0; s < G.nstrips; s++) {
+    // the strip's 16 target symbols
+    uint32_t t[16];
+    {
+      u4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+      if (s * 16 < T) {
+        const gptr<const u4> tp = (gptr<const u4>)(pool + P.toff + s * 16);
+        a = tp[0];
+        b = tp[1];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        const uint32_t v = c < 8 ? sym8(a, c) : sym8(b, c - 8);
+        t[c] = (s * 16 + (uint32_t)c < T) ? v : kSentT;
+      }
+    }
+    uint32_t H[16], colkey[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) H[c] = 0, colkey[c] = 0;
+    uint32_t hdiag = 0;  // H(r - 1, first column - 1)
+    // boundary column and query symbols of the first block
+    uint32_t hbn[8];
+    u4 qn = {0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; i++) hbn[i] = s ? hb[(size_t)i * 64] : 0u;
+    if (0 < Q) qn = *(gptr<const u4>)(pool + P.qoff);
+    for (uint32_t rb = 0; rb < nblk; rb++) {
+      uint32_t hbc[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) hbc[i] = hbn[i];
+      const u4 qc = qn;
+      if (rb + 1 < nblk) {  // next block's inputs, in flight while this one is computed
+        if (s) {
+#pragma unroll
+          for (int i = 0; i < 8; i++) hbn[i] = hb[(size_t)((rb + 1) * 8 + i) * 64];
+        }
+        if ((rb + 1) * 8 < Q) qn = *(gptr<const u4>)(pool + P.qoff + (rb + 1) * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const uint32_t r = rb * 8 + (uint32_t)i;
+        const uint32_t q = r < Q ? sym8(qc, i) : kSentQ;
+        uint32_t acc = 0, hright;
+        lane_row(q, t, H, colkey, hbc[i], hdiag, 0xffffu - r, K, acc, hright);
+        hdiag = hbc[i];
+        dirs[((size_t)s * G.Qmax + r) * 64] = acc;
+        hb[(size_t)r * 64] = hright;
+      }
+    }
+    // fold the strip's column records into the lane's best cell
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+      const uint32_t v = colkey[c] >> 16;
+      const uint32_t x = 0x10000u - (colkey[c] & 0xffffu);  // row + 1
+      const uint32_t j = s * 16 + (uint32_t)c + 1;
+      const uint32_t key = ((x + j) << 16) | x;
+      const bool better = v > bestH || (v == bestH && v > 0 && key < bestkey);
+      bestH = better ? v : bestH;
+      bestkey = better ? key : bestkey;
+    }
+  }
+  if (Q) {
+    LaneOut o;
+    o.score = (int32_t)bestH;
+    o.bx = bestH ? (bestkey & 0xffffu) : 0;
+    o.bj = bestH ? ((bestkey >> 16) - (bestkey & 0xffffu)) : 0;
+    o.nops = 0;
+    W.outs[P.pair] = o;
+  }
+}
+
+// Traceback: one LANE per pair follows the direction bits from the best cell until H reaches 0
+// (rust/src/algorithm/mod.rs:663-664) or an edge (:650).  ops[] receives, last alignment column first:
+// 0 = (q[x-1], t[j-1]), 1 = (q[x-1], '-'), 2 = ('-', t[j-1]) -- the walker of sw_exact.hip's convention.
+// The walk is a chain of dependent loads (one direction word per move), tens of thousands of chains in flight.
+__global__ void __launch_bounds__(64) sw_lanes_walk_kernel(LanesWork W, int match, int miss, int gap) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t g = blockIdx.x;
+  if (g >= W.n_groups) return;
+  const LaneGroup G = W.groups[g];
+  const LanePair P = W.lanes[(size_t)g * 64 + lane];
+  if (!P.Q) return;
+  const gptr<const uint16_t> pool = (gptr<const uint16_t>)W.pool;
+  const gptr<const uint32_t> dirs = (gptr<const uint32_t>)W.dirs + G.dirs_off + lane;
+  const gptr<uint8_t> ops = (gptr<uint8_t>)W.ops + P.ops_off;
+  LaneOut o = W.outs[P.pair];
+  int H = o.score;
+  uint32_t x = o.bx, j = o.bj, n = 0;
+  const uint32_t cap = P.Q + P.T;
+  while (H > 0 && x > 0 && j > 0 && n < cap) {
+    const uint32_t r = x - 1, cj = j - 1;
+    const uint32_t w = dirs[((size_t)(cj >> 4) * G.Qmax + r) * 64];
+    const uint32_t code = (w >> ((cj & 15u) * 2)) & 3u;
+    uint32_t op;
+    if (code == 3u) {
+      H -= (pool[P.qoff + r] == pool[P.toff + cj]) ? match : miss;
+      x--;
+      j--;
+      op = 0;
+    } else if (code == 2u) {
+      H -= gap;
+      x--;
+      op = 1;
+    } else if (code == 1u) {
+      H -= gap;
+      j--;
+      op = 2;
+    } else {
+      break;  // (code 0 with H > 0 cannot happen: every cell on the path had a winning candidate)
+    }
+    ops[n++] = (uint8_t)op;
+  }
+  W.outs[P.pair].nops = n;
+}
+
+hipError_t launch_lanes(const LanesWork& w, Scoring sc, bool want_trace, hipStream_t stream) {
+  if (w.n_groups == 0) return hipSuccess;
+  hipLaunchKernelGGL(sw_lanes_kernel, dim3(w.n_groups), dim3(64), 0, stream, w, sc.match, sc.miss, sc.gap);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || !want_trace) return e;
+  hipLaunchKernelGGL(sw_lanes_walk_kernel, dim3(w.n_groups), dim3(64), 0, stream, w, sc.match, sc.miss, sc.gap);
+  return hipGetLastError();
+}
+
+}  // namespace swhip

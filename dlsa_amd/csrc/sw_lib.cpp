@@ -1108,6 +1108,14 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
     if (rc) return rc;
     tm.lap("windows");
   }
+  // Big batches of short pairs: one pair per lane (sw_lanes.hip) instead of one 256-row strip per wave.
+  if (path != SW_PATH_STRAIGHT && !specs.empty()) {
+    std::vector<uint8_t> small(specs.size());
+    for (size_t k = 0; k < specs.size(); k++) small[k] = dec[qi[idx[k]]].ascii && dec[ti[idx[k]]].ascii;
+    const int rc = align_lanes(device, specs.data(), specs.size(), small.data(), sc, po.data(), arena, handled.data());
+    if (rc) return rc;
+    tm.lap("lanes");
+  }
   // Results of pairs [k_lo, k_hi) as ONE slab: [Slab | ResultBox x pairs | per pair: StrHdr + query alignment + NUL,
   // StrHdr + target alignment + NUL].  ASCII pairs (the normal case) know their string lengths up front (= the
   // number of traceback ops); a pair with non-ASCII symbols re-encodes to UTF-8 and keeps heap strings of its own.

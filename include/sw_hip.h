@@ -193,6 +193,12 @@ struct sw_kernel_stats {
   uint32_t score_packed_per_row, score_aux_per_2rows; /* read off the generated loop (sw_score_asm.inc) */
   uint32_t score_workgroups;   /* persistent workgroups of the last launch */
   uint32_t pad_;
+  /* the one-pair-per-lane exact kernel (batches of short pairs, sw_lanes.hip); its time is ALSO part of
+     exact_kernel_ms and its cells of exact_cells */
+  double lanes_kernel_ms;      /* fill + traceback walker */
+  uint64_t lanes_cells;        /* sum Q*T (unpadded) of the pairs it answered */
+  uint64_t lanes_padded_cells; /* cells its waves computed: 64 x rows x 16 x strips per group */
+  uint64_t lanes_pairs;
 };
 int sw_hip_last_stats(struct sw_kernel_stats *out);
 

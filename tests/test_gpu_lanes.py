@@ -1,0 +1,166 @@
+"""GPU parity of the one-pair-per-lane exact kernel (dlsa_amd/csrc/sw_lanes.hip) against the oracle, through the C ABI
+(sw_align_batch): random reads, the padded-length quirks (T % 64 == 0), ties between maximal cells, pairs the kernel
+must hand back to the whole-matrix path, and the automatic choice for a big batch.  SW_HIP_LANES=1 forces the lane
+path for every eligible pair (the library reads the variable at every call), 0 forbids it."""
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PATHS = {0: "lowmem", 1: "simd"}
+
+
+@pytest.fixture
+def lanes_env():
+    old = os.environ.get("SW_HIP_LANES")
+    yield lambda v: os.environ.__setitem__("SW_HIP_LANES", v)
+    if old is None:
+        os.environ.pop("SW_HIP_LANES", None)
+    else:
+        os.environ["SW_HIP_LANES"] = old
+
+
+def _rnd(rng, n, alpha="ACGT"):
+    return "".join(rng.choice(alpha) for _ in range(n))
+
+
+def _tuple(r):
+    return None if r is None else (r.query, r.target, r.score, r.max_x, r.max_y)
+
+
+def _expect(oracle, path, q, t, sc):
+    e = oracle.align(PATHS[path], q, t, *sc)
+    return None if e is None else (e["q"], e["t"], e["score"] & 0xFFFF, e["max_x"], e["max_y"])
+
+
+def _run(qs, ts, sc, path):
+    import dlsa_amd
+    from dlsa_amd import bridge
+    gap, match, miss = sc
+    before = bridge.last_stats()["lanes_pairs"]
+    res = bridge.align_batch(qs, ts, dlsa_amd.AlignmentScore(match, miss, gap), path)
+    return res, bridge.last_stats()["lanes_pairs"] - before
+
+
+def _check_all(oracle, qs, ts, sc, path, res):
+    for i, (q, t) in enumerate(zip(qs, ts)):
+        assert _tuple(res[i]) == _expect(oracle, path, q, t, sc), (i, path, sc, len(q), len(t), q, t)
+
+
+@pytest.mark.parametrize("sc", [(-1, 2, -1), (-2, 1, -1), (-3, 5, -2), (-1, 1, -1), (-5, 4, -1)])
+def test_random_reads_both_entries(oracle, lanes_env, sc):
+    lanes_env("1")
+    rng = random.Random(101 + sc[1])
+    for path in (0, 1):
+        qs, ts = [], []
+        for _ in range(400):
+            n, m = rng.randint(1, 210), rng.randint(1, 210)
+            q = _rnd(rng, n)
+            if rng.random() < 0.5:   # a mutated copy: long alignments with gaps
+                t = "".join(c if rng.random() > 0.12 else rng.choice("ACGT-") for c in q).replace("-", "")[:m] or "A"
+            else:
+                t = _rnd(rng, m)
+            qs.append(q)
+            ts.append(t)
+        res, n_lane = _run(qs, ts, sc, path)
+        assert n_lane > 300, n_lane   # (a few tiny ring-path pairs with T < Qp are not eligible)
+        _check_all(oracle, qs, ts, sc, path, res)
+
+
+def test_padded_length_quirks_and_hand_back(oracle, lanes_env):
+    """T % 64 == 0 on the full-matrix path: the last column is skipped except H(1, T) (rust/src/algorithm/mod.rs:98,
+    134,178); the lane kernel leaves that one cell out and hands the pair back when it could matter (score <= match)."""
+    lanes_env("1")
+    rng = random.Random(7)
+    sc = (-1, 2, -1)
+    qs, ts = [], []
+    for T in (64, 128, 192):
+        for Q in (33, 40, 64, 65, 100, 128, 129, 190):
+            qs.append(_rnd(rng, Q)); ts.append(_rnd(rng, T))
+            qs.append("A" * Q); ts.append("C" * (T - 1) + "A")       # only H(1, T) scores
+            qs.append("A" + "G" * (Q - 1)); ts.append("C" * (T - 1) + "A")
+            qs.append("G" * Q); ts.append("C" * T)                   # no hit at all
+            q = _rnd(rng, Q); qs.append(q); ts.append((q * 4)[:T])  # the alignment runs into the skipped column
+    for path in (0, 1):
+        res, n_lane = _run(qs, ts, sc, path)
+        assert n_lane > 0
+        _check_all(oracle, qs, ts, sc, path, res)
+
+
+def test_ties_take_the_reference_first_cell(oracle, lanes_env):
+    """Several cells reach the maximum: smallest x + j first, then smallest x (rust/src/lib.rs:122), across columns
+    of one strip, across strips and across rows."""
+    lanes_env("1")
+    rng = random.Random(9)
+    sc = (-1, 2, -1)
+    qs, ts = [], []
+    for _ in range(150):
+        frag = _rnd(rng, rng.randint(3, 12))
+        n_rep = rng.randint(2, 5)
+        fill = lambda k: "".join(rng.choice("NX") for _ in range(k))  # noqa: E731  (never matches a fragment)
+        q = fill(rng.randint(0, 30)) + frag + fill(rng.randint(0, 40)) + (frag if rng.random() < 0.5 else "") + fill(rng.randint(0, 9))
+        t = fill(rng.randint(0, 20)).lower()
+        for _ in range(n_rep):
+            t += frag + fill(rng.randint(1, 35)).lower()
+        qs.append(q); ts.append(t)
+        qs.append(t); ts.append(q)
+    for path in (0, 1):
+        res, n_lane = _run(qs, ts, sc, path)
+        assert n_lane > 0
+        _check_all(oracle, qs, ts, sc, path, res)
+
+
+def test_mixed_batch_with_ineligible_pairs(oracle, lanes_env):
+    lanes_env("1")
+    rng = random.Random(11)
+    sc = (-1, 2, -1)
+    qs, ts = [], []
+    for i in range(200):
+        q, t = _rnd(rng, rng.randint(20, 160)), _rnd(rng, rng.randint(20, 160))
+        if i % 7 == 0:
+            q = q[:10] + "é" + q[10:]          # not ASCII: whole-matrix path
+        if i % 11 == 0:
+            t = _rnd(rng, 3000)                 # ring path, long target
+        if i % 13 == 0:
+            q, t = _rnd(rng, 20), _rnd(rng, 45)  # ring path with T < Qp: two-phase discovery order
+        qs.append(q); ts.append(t)
+    res, n_lane = _run(qs, ts, sc, 0)
+    assert 0 < n_lane < 200
+    _check_all(oracle, qs, ts, sc, 0, res)
+
+
+def test_lane_path_equals_whole_matrix_path_on_1kb_pairs(oracle, lanes_env):
+    """Longer pairs (many strips, boundary column through HBM): both paths of the library and a sample of the oracle."""
+    rng = random.Random(13)
+    sc = (-1, 2, -1)
+    qs = [_rnd(rng, rng.randint(700, 1100)) for _ in range(96)]
+    ts = [_rnd(rng, rng.randint(700, 1100)) for _ in range(96)]
+    for k in range(0, 96, 3):  # related pairs
+        ts[k] = "".join(c if rng.random() > 0.1 else rng.choice("ACGT") for c in qs[k])[: len(ts[k])]
+    lanes_env("1")
+    a, n_lane = _run(qs, ts, sc, 0)
+    assert n_lane == 96
+    lanes_env("0")
+    b, n0 = _run(qs, ts, sc, 0)
+    assert n0 == 0
+    assert [_tuple(x) for x in a] == [_tuple(x) for x in b]
+    for i in range(0, 96, 8):
+        assert _tuple(a[i]) == _expect(oracle, 0, qs[i], ts[i], sc)
+
+
+def test_big_batch_of_reads_takes_the_lane_path_by_itself(oracle, lanes_env):
+    lanes_env("auto")
+    rng = random.Random(17)
+    sc = (-1, 2, -1)
+    reads = [_rnd(rng, 150) for _ in range(300)]
+    qs = [reads[rng.randrange(300)] for _ in range(20000)]
+    ts = [reads[rng.randrange(300)] if rng.random() < 0.9 else _rnd(rng, rng.randint(100, 150)) for _ in range(20000)]
+    res, n_lane = _run(qs, ts, sc, 0)
+    assert n_lane == 20000
+    for i in range(0, 20000, 97):
+        assert _tuple(res[i]) == _expect(oracle, 0, qs[i], ts[i], sc), i
+    lanes_env("0")
+    ref, _ = _run(qs[:4000], ts[:4000], sc, 0)
+    assert [_tuple(x) for x in res[:4000]] == [_tuple(x) for x in ref]
