@@ -105,6 +105,16 @@ def cpu_baseline(bridge, main_query, main_flat, main_offsets, n_total):
     return main
 
 
+def _sum_stats(per_shard):
+    """Counters of a sharded search: sums over the shards; per-launch constants are taken from shard 0."""
+    out = dict(per_shard[0])
+    for st in per_shard[1:]:
+        for k, v in st.items():
+            if k not in ("score_packed_per_row", "score_aux_per_2rows", "score_workgroups", "pad_"):
+                out[k] += v
+    return out
+
+
 def load_pmc_traffic(key):
     """HBM bytes per score-kernel launch from the committed PMC passes (profiles/r02_pmc.json), if the workload is
     one that was profiled; counters cannot be read from inside this process."""
@@ -217,7 +227,7 @@ def main():
     def step():
         if ndb is not None:
             hits = ndb.search_topk_batch(queries, score, TOP_K)
-            st = ndb.last_stats(0)
+            st = _sum_stats([ndb.last_stats(i) for i in range(args.node_shards)])
         else:
             hits = db.search_topk_batch(queries, score, TOP_K)
             st = bridge.last_stats()

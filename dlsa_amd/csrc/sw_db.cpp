@@ -44,6 +44,9 @@ struct sw_db {
                                                           // in flight keeps its own reference: PersistPass)
   std::vector<uint32_t> generic;  // targets scored by the exact kernel only
   uint32_t max_len = 0;
+  // counters of THIS database's last search (phase A resets, phase B adds): several logical shards may share one
+  // device context, whose own counters then belong to whichever shard ran last
+  sw_kernel_stats last_stats{};
 };
 
 namespace {
@@ -1148,6 +1151,7 @@ size_t swhip::db_persist_ring_bytes(const sw_db* db, uint32_t Q, int cus) {
 
 // ---- the two phases of a search (used by the single-database entry points below and by sw_node.cpp) -------------
 Context* swhip::db_context(sw_db* db) { return db ? db->ctx : nullptr; }
+const sw_kernel_stats& swhip::db_last_stats(const sw_db* db) { return db->last_stats; }
 
 int swhip::db_topk_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring sc, size_t k,
                          std::vector<std::vector<TopEntry>>& tops) {
@@ -1191,6 +1195,7 @@ int swhip::db_topk_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring s
     if (rc) return rc;
     q = hi;
   }
+  db->last_stats = L.c->stats;
   return SW_OK;
 }
 
@@ -1216,8 +1221,12 @@ int swhip::db_align_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring 
   {
     CtxLock L(db->ctx);
     if (L.rc) return L.rc;
+    const double ms0 = L.c->stats.exact_kernel_ms;
+    const uint64_t cells0 = L.c->stats.exact_cells;
     const int rc = run_exact(*L.c, L.c->ws, specs.data(), total, sc, true, po.data(), &arena);
     if (rc) return rc;
+    db->last_stats.exact_kernel_ms += L.c->stats.exact_kernel_ms - ms0;
+    db->last_stats.exact_cells += L.c->stats.exact_cells - cells0;
   }
   for (size_t i = 0; i < total; i++) {
     const HitRef& r = refs[i];

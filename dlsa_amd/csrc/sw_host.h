@@ -375,6 +375,7 @@ int db_topk_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring sc, size
 // (target_index = the database-local index; strings owned by the caller).  Takes the context lock.
 int db_align_phase(sw_db* db, const std::vector<QueryPrep>& qps, Scoring sc, const std::vector<HitRef>& refs, sw_hit* hits_out);
 Context* db_context(sw_db* db);
+const sw_kernel_stats& db_last_stats(const sw_db* db);  // counters of the database's own last search
 // A score pass that leaves every inter-unit boundary column resident (ring slot = ticket) and reports, per strip
 // of the stream, the packed maxima of that strip alone.  Pointers stay valid until the next pass on the context.
 struct PersistPass {

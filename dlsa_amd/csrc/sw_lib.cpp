@@ -114,6 +114,17 @@ int ctx_create(int device, Context** out) {
   if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
     return fail(SW_E_NOGPU, std::string("device is ") + prop.gcnArchName + ", the kernels are built for gfx950 only");
   std::unique_ptr<Context> c(new Context);
+  // a failure below must not leave the stream, the events or the host arena behind (a caller may retry)
+  struct Undo {
+    Context* c;
+    ~Undo() {
+      if (!c) return;
+      for (hipEvent_t e : {c->ev0, c->ev1, c->ev2, c->ev3})
+        if (e) (void)hipEventDestroy(e);
+      if (c->stream) (void)hipStreamDestroy(c->stream);
+      if (c->na_host.base) (void)hipHostFree(c->na_host.base);
+    }
+  } undo{c.get()};
   c->device = device;
   c->cus = prop.multiProcessorCount;
   HIPCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -147,12 +158,16 @@ int ctx_create(int device, Context** out) {
     for (DevBuf* b : {&c->na.dirs, &c->na.sel_hist, &c->na.sel_ctr, &c->na.sel_rerun, &c->na.sel_cand, &c->na.sel_tie})
       b->bind_fixed(nullptr, 0);
   }
-  c->na_host.base = (unsigned char*)malloc(kNaHostBytes);
-  if (!c->na_host.base) return fail(SW_E_NOMEM, "out of host memory");
+  // page-locked, so that the entry point's copies are truly asynchronous and the runtime has nothing to stage
+  void* arena = nullptr;
+  if (hipHostMalloc(&arena, kNaHostBytes, hipHostMallocPortable) != hipSuccess || !arena)
+    return fail(SW_E_NOMEM, "out of page-locked host memory");
+  c->na_host.base = (unsigned char*)arena;
   c->na_host.cap = kNaHostBytes;
   c->na.h_in.bind_fixed(nullptr, 0);
   c->na.h_out.bind_fixed(nullptr, 0);
   reset_stats(*c);
+  undo.c = nullptr;
   *out = c.release();
   return SW_OK;
 }
@@ -998,6 +1013,8 @@ void swhip::parallel_ranges_impl(size_t n, unsigned nt, void (*fn)(void*, size_t
       }
       P.helpers++;
     }
+    // (room first: a push_back that throws half-way would unwind `job` while queued tasks still point at it)
+    P.tasks.reserve(P.tasks.size() + nt);
     for (unsigned t = 1; t < nt; t++) P.tasks.push_back(PoolTask{&job, n * t / nt, n * (t + 1) / nt});
   }
   P.work_cv.notify_all();

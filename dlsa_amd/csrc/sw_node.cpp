@@ -461,9 +461,9 @@ int sw_node_search_topk_batch(sw_node_db* ndb, const char* const* queries, size_
 
 int sw_node_last_stats(const sw_node_db* ndb, int shard, sw_kernel_stats* out) {
   if (!ndb || !out || shard < 0 || (size_t)shard >= ndb->shards.size()) return fail(SW_E_ARG, "bad argument");
-  CtxLock L(ndb->ctx[shard]);
+  CtxLock L(ndb->ctx[shard]);  // (no search of this shard is running while its counters are read)
   if (L.rc) return L.rc;
-  *out = L.c->stats;
+  *out = db_last_stats(ndb->shards[shard]);
   return SW_OK;
 }
 

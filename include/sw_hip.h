@@ -118,13 +118,16 @@ int sw_db_scores(sw_db *db, const char *query, struct AlignmentScores scores, in
 void sw_hits_free(struct sw_hit *hits, int n_hits);
 
 /* ---- the one entry point that allocates nothing --------------------------------------------------------------
- * No counterpart in the reference.  For callers that cannot call hipMalloc: code under HIP graph capture, tight
- * serving loops, harnesses that forbid allocation.  sw_db_scores for the same arguments, with the same result,
+ * No counterpart in the reference.  For callers that cannot call hipMalloc: tight serving loops, harnesses that
+ * forbid allocation, code that runs while another stream of the process is under HIP graph capture (an allocation
+ * there would invalidate the capture).  The call itself is NOT capturable: it synchronises its own stream, reads
+ * event timers and finishes on the host.  sw_db_scores for the same arguments, with the same result,
  * but every byte its kernels need beyond the inputs (the resident database, the query) and the output lives in a
  * file-scope device array of sw_hip_noalloc_scratch_bytes() bytes (96 MiB; every GPU the library runs on holds
- * its own copy until the process ends) and in a host arena reserved when the device's context is set up
- * (sw_hip_init / first use of the device).  The call performs no hipMalloc, hipFree, hipHostMalloc or any other
- * allocating routine, on the device or on the host.  Limits, each an error (SW_E_LIMIT / SW_E_DOMAIN with a
+ * its own copy until the process ends) and in a page-locked host arena reserved when the device's context is set
+ * up (sw_hip_init / first use of the device), so its copies are asynchronous and the runtime stages nothing.  The
+ * call performs no hipMalloc, hipFree or hipHostMalloc; only an error path builds a message string on the host
+ * heap.  Limits, each an error (SW_E_LIMIT / SW_E_DOMAIN with a
  * message), never a fallback to allocation:
  *   - scoring with match > 0, mismatch < 0, gap < 0; query and every non-empty database sequence over ACGT only
  *     (the packed kernel's domain; anything else: use sw_db_scores);
@@ -217,7 +220,8 @@ int sw_node_align_batch(const sw_node *node, const char *const *queries, const c
 /* The same for a whole node: every distinct device of the handle runs the benchmark at the same time and the
  * figures are added -- the number a one-process-per-node GPU worker registers with the master. */
 float sw_node_benchmark_cups(sw_node *node);
-/* sw_hip_last_stats for one shard of a node database (its device's last submission). */
+/* sw_hip_last_stats for one shard of a node database: the counters of THAT shard's last search (logical shards
+ * that share a device do not overwrite each other); a caller adds the shards up. */
 int sw_node_last_stats(const sw_node_db *db, int shard, struct sw_kernel_stats *out);
 
 /* ---- test hook (no GPU needed) ------------------------------------------------------------------------ */

@@ -75,6 +75,9 @@ func (w *Worker) ExecuteWorkGPU(work *CompleteWorkPackage, queries []QueryTarget
 	// one C string per distinct sequence of the package; pairs name them by index
 	index := make(map[SequenceId]C.uint32_t, len(work.Sequences))
 	nSeq := len(work.Sequences)
+	if nSeq == 0 { // pairs without sequences: the reference stops the same way (worker_impl.go:119-122)
+		log.Fatalf("Target and query not found in work package")
+	}
 	seqs := (*[1 << 30]*C.char)(C.malloc(C.size_t(nSeq) * C.size_t(unsafe.Sizeof((*C.char)(nil)))))[:nSeq:nSeq]
 	i := 0
 	defer func() { // (one deferred call, not one per sequence: a package holds 10^5 of them)
@@ -130,6 +133,9 @@ func (w *Worker) ExecuteWorkGPU(work *CompleteWorkPackage, queries []QueryTarget
 	buf := WorkResult{Alignments: make([]AlignmentDetail, 0, bufferSize+1)}
 	for idx, comb := range queries {
 		d := &out[idx]
+		if d.entry < 0 { // no entry point produced a result: nothing is posted for this pair (include/sw_worker.h),
+			continue // the master re-schedules what stays missing
+		}
 		buf.Alignments = append(buf.Alignments, AlignmentDetail{
 			Alignment: Alignment{
 				QueryAlignment:  C.GoString(d.query_alignment),

@@ -12,7 +12,9 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.mark.parametrize("world,n,k,nq", [(2, 1001, 5, 4), (3, 64, 7, 2), (2, 3, 5, 1)])
+@pytest.mark.parametrize("world,n,k,nq", [(2, 1001, 5, 4), (3, 64, 7, 2), (2, 3, 5, 1),
+                                          # ranks that own fewer than k targets, and ranks that own none at all
+                                          (3, 2, 5, 2), (4, 1, 3, 1)])
 def test_sharded_topk_merge(tmp_path, world, n, k, nq):
     from dlsa_amd import build
     build.build()
