@@ -253,12 +253,24 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
     return (col <= T) ? (int)gt[col - 1] : 0x20000;
   };
   int bnext = fetch_bnd(0), tnext = fetch_t(0);
+  const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + W.wait_ticks;
+  // (test hook, ExactWork::debug_drop: the first strip of the first pair never publishes its bottom row)
+  const bool publish = feeds && !(W.debug_drop && strip == 0 && P.first_unit == 0);
   for (uint32_t g = 0; g < NG; g++) {
-    // the boundary of this block must be complete; normally it is (fetched 16 steps ago)
+    // The boundary of this block must be complete; normally it is (fetched 16 steps ago).  The wait is bounded in
+    // TIME (s_memrealtime, 100 MHz), not in iterations; when it runs out -- a bug, not a legal state: the strip above
+    // holds an earlier ticket -- the wave stores the error word and ENDS on the spot (it never computes on with an
+    // incomplete boundary), and every other waiting wave sees the word and ends too: the grid drains, the host
+    // reads the word with the results (exact_chunk_end) and reports SW_E_HIP.  Both conditions are wave-uniform
+    // (scalar branch: s_endpgm must not sit behind an EXEC mask).
     for (uint32_t spin = 0; __builtin_amdgcn_ballot_w64(((uint32_t)bnext & kTag) == 0) != 0; spin++) {
-      if (spin >= (1u << 22)) {  // a bug, not a legal state: let the grid drain and report
-        __hip_atomic_store(W.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
+      if ((spin & 63u) == 63u) {
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(W.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const bool late = __builtin_amdgcn_s_memrealtime() >= deadline;
+        if (e != 0 || late) {
+          if (e == 0) __hip_atomic_store(W.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_endpgm" ::: "memory");
+        }
       }
       __builtin_amdgcn_s_sleep(SW_EXACT_SLEEP);
       bnext = fetch_bnd(g);
@@ -281,7 +293,7 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
 #pragma unroll
       for (int r = 0; r < RPL; r++) w[r * 64] = acc[r];
     }
-    if (feeds && lane == 63) {
+    if (publish && lane == 63) {
       // lane 63 finished columns 16 g - 62 .. 16 g - 47 of the strip's bottom row during this block: four 16-byte
       // device-scope stores (a wave may only have 63 memory operations in flight; sixteen dword stores per block
       // on top of the direction words made the producer wait for its own stores)

@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -296,8 +297,12 @@ int align_windows(const std::vector<Decoded>& dec, const std::vector<uint32_t>& 
 // it is eligible for and that its cost model prefers (po[k], ops appended to `arena`, handled[k] = 1), leaves the
 // rest alone.  small_syms[k]: every symbol of both sequences is below 0xfffe (the kernel's sentinels).  Takes the
 // lock of `device`'s context itself.
+// `ready(ks, m)` is called once per finished slice of the batch with the indices of the pairs it answered, while
+// the next slice is on the GPU (the arena does not move until the call returns: the ops of every slice have their
+// place in it from the start).
+using LanesReady = std::function<void(const uint32_t* ks, size_t m)>;
 int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* small_syms, Scoring sc, PairOut* po,
-                OpsArena& arena, uint8_t* handled);
+                OpsArena& arena, uint8_t* handled, const LanesReady& ready = nullptr);
 // A batch of pairs on one device (sw_lib.cpp): the body of sw_align_batch.  out[i] = NULL for a pair the reference
 // would have failed on; a non-zero return means nothing was handed over.
 int align_many_on(int device, const char* const* queries, const char* const* targets, size_t n, AlignmentScores as,

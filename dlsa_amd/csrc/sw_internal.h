@@ -125,7 +125,9 @@ struct ExactWork {
   ExactRec* recs;       // per ticket
   uint32_t* pair_done;  // per pair: strips finished (zeroed)
   uint32_t* ticket;     // work counter (zeroed)
-  uint32_t* err;        // != 0: a hand-over wait timed out (zeroed)
+  uint32_t* err;        // != 0: a hand-over wait timed out (zeroed); the waiting waves have ended, results are void
+  unsigned long long wait_ticks;  // budget of a hand-over wait in s_memrealtime ticks (100 MHz)
+  uint32_t debug_drop;  // test hook: strip 0 of pair 0 never publishes its bottom row (SW_HIP_DEBUG_DROP_HANDOVER)
 };
 hipError_t launch_exact(const ExactWork& w, Scoring sc, hipStream_t stream);
 hipError_t launch_walk(const ExactPair* d_pairs, ExactOut* d_outs, uint32_t n_pairs, int rpl, Scoring sc,

@@ -32,7 +32,7 @@ struct Elig {
 }  // namespace
 
 int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* small_syms, Scoring sc, PairOut* po,
-                OpsArena& arena, uint8_t* handled) {
+                OpsArena& arena, uint8_t* handled, const LanesReady& ready) {
   const int mode = lanes_mode();
   if (mode == 0 || n == 0) return SW_OK;
   // the kernel's domain: sentinel cells lose only if every step off a match costs something
@@ -89,25 +89,64 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
   CtxLock L(device);
   if (L.rc) return L.rc;
   Context& c = *L.c;
-  Workspace& ws = c.ws;
-  int erc = SW_OK;
-  for (hipEvent_t* e : {&ws.ev_k0, &ws.ev_k1, &ws.ev_done})
-    if (!*e && hipEventCreate(e) != hipSuccess) return fail(SW_E_HIP, "hipEventCreate");
+  Workspace* wss[2] = {&c.ws, &c.ws2};
+  for (Workspace* w : wss)
+    for (hipEvent_t* e : {&w->ev_k0, &w->ev_k1, &w->ev_done})
+      if (!*e && hipEventCreate(e) != hipSuccess) return fail(SW_E_HIP, "hipEventCreate");
 
-  // slices of groups that fit the scratch budget (direction words dominate: rows x strips x 256 bytes per group)
-  size_t g0 = 0;
-  while (g0 < n_groups) {
-    size_t g1 = g0, dir_words = 0, hb_words = 0, ops_bytes = 0;
-    while (g1 < n_groups) {
-      const size_t dw = (size_t)groups[g1].Qmax * groups[g1].nstrips * 64, hw = (size_t)groups[g1].Qmax * 64;
-      if (g1 > g0 && (dir_words + dw + hb_words + hw) * 4 > c.scratch_budget) break;
-      groups[g1].dirs_off = dir_words;
-      groups[g1].hb_off = hb_words;
-      dir_words += dw;
-      hb_words += hw;
-      g1++;
+  // Slices of groups: each fits the scratch budget (direction words dominate: rows x strips x 256 bytes per group),
+  // and a big batch is cut into a few slices anyway so that TWO are in flight -- while slice i is on the GPU, slice
+  // i + 1 is staged and queued behind it on the second workspace, and the caller's `ready` (string assembly, on
+  // another thread) works on slice i - 1.
+  struct Slice {
+    size_t g0 = 0, g1 = 0, dir_words = 0, hb_words = 0, ops_base = 0, ops_bytes = 0;
+    std::vector<LanePair> lanes;
+    uint64_t cells = 0;
+  };
+  std::vector<Slice> slices;
+  {
+    const size_t want = el.size() >= 32768 ? std::min<size_t>(16, std::max<size_t>(2, el.size() / 50000)) : 1;  // (a slice should still fill the GPU: >= 400 waves)
+    const size_t per = (n_groups + want - 1) / want;
+    size_t g0 = 0;
+    while (g0 < n_groups) {
+      Slice sl;
+      sl.g0 = g0;
+      size_t g1 = g0;
+      while (g1 < n_groups && g1 - g0 < per) {
+        const size_t dw = (size_t)groups[g1].Qmax * groups[g1].nstrips * 64, hw = (size_t)groups[g1].Qmax * 64;
+        if (g1 > g0 && (sl.dir_words + dw + sl.hb_words + hw) * 4 > c.scratch_budget / 2) break;
+        groups[g1].dirs_off = sl.dir_words;
+        groups[g1].hb_off = sl.hb_words;
+        sl.dir_words += dw;
+        sl.hb_words += hw;
+        g1++;
+      }
+      sl.g1 = g1;
+      slices.push_back(std::move(sl));
+      g0 = g1;
     }
-    const size_t p0 = g0 * 64, p1 = std::min(el.size(), g1 * 64), np = p1 - p0, ng = g1 - g0;
+  }
+  // the traceback ops of ALL slices: one stretch of the arena, sized once, so that nothing moves while `ready` reads
+  // the finished slices
+  size_t total_ops = 0;
+  for (Slice& sl : slices) {
+    sl.ops_base = total_ops;
+    const size_t p0 = sl.g0 * 64, p1 = std::min(el.size(), sl.g1 * 64);
+    for (size_t i = p0; i < p1; i++) total_ops += ((size_t)el[i].Q + specs[el[i].k].T + 15) & ~(size_t)15;
+  }
+  const size_t arena_base = arena.size();
+  arena.resize(arena_base + total_ops);  // (page-locked: the copies land in place)
+  tm.lap("lanes: slices");
+
+  struct InFlight {
+    size_t np = 0;
+  } fl[2];
+  auto align64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
+  // stages slice `si` and queues it (copies in, kernels, copies out) on workspace `ws`; does not wait
+  auto begin = [&](size_t si, Workspace& ws, InFlight& f) -> int {
+    Slice& sl = slices[si];
+    const size_t p0 = sl.g0 * 64, p1 = std::min(el.size(), sl.g1 * 64), np = p1 - p0, ng = sl.g1 - sl.g0;
+    f.np = np;
     // symbol pool of the slice: every distinct sequence once, 16-byte aligned
     std::unordered_map<const uint16_t*, uint32_t> seen;
     std::vector<uint32_t> by_id;
@@ -132,13 +171,11 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
       else seen[p] = (uint32_t)copies.size() - 1;
       return off;
     };
-    auto align64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
-    std::vector<LanePair> lanes(ng * 64);
-    memset(lanes.data(), 0, lanes.size() * sizeof(LanePair));
-    uint64_t cells = 0;
+    sl.lanes.assign(ng * 64, LanePair{});
+    size_t ops_bytes = 0;
     for (size_t i = p0; i < p1; i++) {
       const PairSpec& s = specs[el[i].k];
-      LanePair& lp = lanes[i - p0];
+      LanePair& lp = sl.lanes[i - p0];
       lp.qoff = add_seq(s.q, s.Q, s.qid);
       lp.toff = add_seq(s.t, s.T, s.tid);
       if (pool_syms > 0x7fffff00u) return fail(SW_E_ARG, "too many symbols in one submission");
@@ -147,24 +184,23 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
       lp.pair = (uint32_t)(i - p0);
       lp.ops_off = ops_bytes;
       ops_bytes += ((size_t)s.Q + s.T + 15) & ~(size_t)15;
-      cells += (uint64_t)s.Q * s.T;
+      sl.cells += (uint64_t)s.Q * s.T;
     }
+    sl.ops_bytes = ops_bytes;
     pool_syms += 64;  // (the kernel loads 32 bytes at a sequence's last 16-symbol boundary)
-    const size_t in_groups = 0, in_lanes = align64(ng * sizeof(LaneGroup)), in_pool = in_lanes + align64(lanes.size() * sizeof(LanePair));
+    const size_t in_groups = 0, in_lanes = align64(ng * sizeof(LaneGroup)), in_pool = in_lanes + align64(sl.lanes.size() * sizeof(LanePair));
     const size_t in_bytes = in_pool + align64(pool_syms * 2);
     const size_t out_ops = align64(np * sizeof(LaneOut)), out_bytes = out_ops + align64(ops_bytes);
+    int erc;
     if ((erc = ws.xin.ensure(in_bytes))) return erc;
     if ((erc = ws.h_in.ensure(in_bytes))) return erc;
-    if ((erc = ws.dirs.ensure(std::max<size_t>(dir_words * 4, 16)))) return erc;
-    if ((erc = ws.xzero.ensure(std::max<size_t>(hb_words * 4, 16)))) return erc;
+    if ((erc = ws.dirs.ensure(std::max<size_t>(sl.dir_words * 4, 16)))) return erc;
+    if ((erc = ws.xzero.ensure(std::max<size_t>(sl.hb_words * 4, 16)))) return erc;
     if ((erc = ws.xout.ensure(out_bytes))) return erc;
     if ((erc = ws.h_out.ensure(out_ops))) return erc;
     uint8_t* const h_in = (uint8_t*)ws.h_in.p;
-    for (size_t g = g0; g < g1; g++) {
-      LaneGroup gg = groups[g];
-      memcpy(h_in + in_groups + (g - g0) * sizeof(LaneGroup), &gg, sizeof(LaneGroup));
-    }
-    memcpy(h_in + in_lanes, lanes.data(), lanes.size() * sizeof(LanePair));
+    memcpy(h_in + in_groups, groups.data() + sl.g0, ng * sizeof(LaneGroup));
+    memcpy(h_in + in_lanes, sl.lanes.data(), sl.lanes.size() * sizeof(LanePair));
     uint16_t* const hpool = (uint16_t*)(h_in + in_pool);
     parallel_ranges(copies.size(), pool_syms * 2, [&](size_t lo, size_t hi) {
       for (size_t k = lo; k < hi; k++) {
@@ -174,8 +210,6 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
       }
     });
     memset(hpool + pool_syms - 64, 0xff, 128);
-    tm.lap("lanes: stage");
-    StreamDrain drain(c.stream);
     HIPCK(hipMemcpyAsync(ws.xin.p, h_in, in_bytes, hipMemcpyHostToDevice, c.stream));
     HIPCK(hipEventRecord(ws.ev_k0, c.stream));
     LanesWork w{};
@@ -190,19 +224,23 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
     HIPCK(launch_lanes(w, sc, true, c.stream));
     HIPCK(hipEventRecord(ws.ev_k1, c.stream));
     HIPCK(hipMemcpyAsync(ws.h_out.p, ws.xout.p, np * sizeof(LaneOut), hipMemcpyDeviceToHost, c.stream));
-    const size_t arena_base = arena.size();
-    arena.resize(arena_base + ops_bytes);  // (page-locked: the copy lands in place)
     if (ops_bytes)
-      HIPCK(hipMemcpyAsync(arena.data() + arena_base, (uint8_t*)ws.xout.p + out_ops, ops_bytes, hipMemcpyDeviceToHost, c.stream));
-    HIPCK(hipStreamSynchronize(c.stream));
-    drain.dismiss();
+      HIPCK(hipMemcpyAsync(arena.data() + arena_base + sl.ops_base, (uint8_t*)ws.xout.p + out_ops, ops_bytes, hipMemcpyDeviceToHost, c.stream));
+    HIPCK(hipEventRecord(ws.ev_done, c.stream));
+    return SW_OK;
+  };
+  // waits for slice `si` and hands its pairs to the caller
+  std::vector<uint32_t> ks;
+  auto end = [&](size_t si, Workspace& ws, InFlight& f) -> int {
+    Slice& sl = slices[si];
+    const size_t p0 = sl.g0 * 64, p1 = p0 + f.np;
+    HIPCK(hipEventSynchronize(ws.ev_done));
     float ms = 0;
     HIPCK(hipEventElapsedTime(&ms, ws.ev_k0, ws.ev_k1));
     c.stats.exact_kernel_ms += ms;
     c.stats.lanes_kernel_ms += ms;
-    tm.lap("lanes: gpu");
     const LaneOut* ho = (const LaneOut*)ws.h_out.p;
-    uint64_t answered = 0;
+    ks.clear();
     for (size_t i = p0; i < p1; i++) {
       const LaneOut& o = ho[i - p0];
       // The path also computes H(1, Tlim + 1) <= match, a cell this kernel leaves out: it can only be the best
@@ -214,20 +252,30 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
       r.bx = o.bx;
       r.bj = o.bj;
       r.nops = o.nops;
-      r.ops_off = arena_base + lanes[i - p0].ops_off;
-      r.end_x = r.end_j = 0;
-      r.end_H = 0;
+      r.ops_off = arena_base + sl.ops_base + sl.lanes[i - p0].ops_off;
       r.key = o.score > 0 ? (((uint64_t)(o.bx + o.bj) << 31) | o.bx) : ~0ull;
       handled[el[i].k] = 1;
-      answered++;
+      ks.push_back(el[i].k);
     }
-    c.stats.exact_cells += cells;
-    c.stats.lanes_cells += cells;
-    c.stats.lanes_pairs += answered;
-    for (size_t g = g0; g < g1; g++) c.stats.lanes_padded_cells += (uint64_t)groups[g].Qmax * groups[g].nstrips * 16 * 64;
-    tm.lap("lanes: results");
-    g0 = g1;
+    c.stats.exact_cells += sl.cells;
+    c.stats.lanes_cells += sl.cells;
+    c.stats.lanes_pairs += ks.size();
+    for (size_t g = sl.g0; g < sl.g1; g++) c.stats.lanes_padded_cells += (uint64_t)groups[g].Qmax * groups[g].nstrips * 16 * 64;
+    std::vector<LanePair>().swap(sl.lanes);
+    if (ready && !ks.empty()) ready(ks.data(), ks.size());
+    return SW_OK;
+  };
+  StreamDrain drain(c.stream);  // (an error return must not leave copies in flight that write the arena or read h_in)
+  int rc = begin(0, *wss[0], fl[0]);
+  for (size_t si = 0; si < slices.size() && !rc; si++) {
+    int rc_next = SW_OK;
+    if (si + 1 < slices.size()) rc_next = begin(si + 1, *wss[(si + 1) & 1], fl[(si + 1) & 1]);
+    rc = end(si, *wss[si & 1], fl[si & 1]);
+    if (!rc) rc = rc_next;
   }
+  if (rc) return rc;
+  drain.dismiss();
+  tm.lap("lanes: submissions");
   (void)padded_cells;
   return SW_OK;
 }

@@ -174,7 +174,7 @@ __global__ void __launch_bounds__(64) sw_lanes_kernel(LanesWork W, int match, in
 // Traceback: one LANE per pair follows the direction bits from the best cell until H reaches 0
 // (rust/src/algorithm/mod.rs:663-664) or an edge (:650).  ops[] receives, last alignment column first:
 // 0 = (q[x-1], t[j-1]), 1 = (q[x-1], '-'), 2 = ('-', t[j-1]) -- the walker of sw_exact.hip's convention.
-// The walk is a chain of dependent loads (one direction word per move), tens of thousands of chains in flight.
+// The walk is a chain of dependent loads, tens of thousands of chains in flight.
 __global__ void __launch_bounds__(64) sw_lanes_walk_kernel(LanesWork W, int match, int miss, int gap) {
   const uint32_t lane = threadIdx.x;
   const uint32_t g = blockIdx.x;
@@ -189,28 +189,51 @@ __global__ void __launch_bounds__(64) sw_lanes_walk_kernel(LanesWork W, int matc
   int H = o.score;
   uint32_t x = o.bx, j = o.bj, n = 0;
   const uint32_t cap = P.Q + P.T;
-  while (H > 0 && x > 0 && j > 0 && n < cap) {
-    const uint32_t r = x - 1, cj = j - 1;
-    const uint32_t w = dirs[((size_t)(cj >> 4) * G.Qmax + r) * 64];
-    const uint32_t code = (w >> ((cj & 15u) * 2)) & 3u;
-    uint32_t op;
-    if (code == 3u) {
-      H -= (pool[P.qoff + r] == pool[P.toff + cj]) ? match : miss;
-      x--;
-      j--;
-      op = 0;
-    } else if (code == 2u) {
-      H -= gap;
-      x--;
-      op = 1;
-    } else if (code == 1u) {
-      H -= gap;
-      j--;
-      op = 2;
-    } else {
-      break;  // (code 0 with H > 0 cannot happen: every cell on the path had a winning candidate)
+  bool broken = false;
+  // A BLOCK of the path per round of loads: the direction words and query symbols of 4 rows up from the current
+  // cell (same strip) and 5 target symbols to its left are fetched together -- 13 independent loads, one memory
+  // latency -- and the walk then runs inside them until it leaves the 4 x 5 block or the strip: about four moves per
+  // latency instead of one.
+  while (H > 0 && x > 0 && j > 0 && n < cap && !broken) {
+    const uint32_t r0 = x - 1, c0 = j - 1, s = c0 >> 4;
+    uint32_t w[4], qs[4], ts[5];
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+      const uint32_t row = r0 >= i ? r0 - i : 0;
+      w[i] = dirs[((size_t)s * G.Qmax + row) * 64];
+      qs[i] = pool[P.qoff + row];
     }
-    ops[n++] = (uint8_t)op;
+#pragma unroll
+    for (uint32_t k = 0; k < 5; k++) ts[k] = pool[P.toff + (c0 >= k ? c0 - k : 0)];
+    uint32_t i = 0, k = 0;  // the current cell is (r0 - i, c0 - k)
+    while (i < 4 && k < 5 && ((c0 - k) >> 4) == s) {
+      const uint32_t wv = i == 0 ? w[0] : (i == 1 ? w[1] : (i == 2 ? w[2] : w[3]));
+      const uint32_t code = (wv >> (((c0 - k) & 15u) * 2)) & 3u;
+      uint32_t op;
+      if (code == 3u) {
+        const uint32_t qv = i == 0 ? qs[0] : (i == 1 ? qs[1] : (i == 2 ? qs[2] : qs[3]));
+        const uint32_t tv = k == 0 ? ts[0] : (k == 1 ? ts[1] : (k == 2 ? ts[2] : (k == 3 ? ts[3] : ts[4])));
+        H -= (qv == tv) ? match : miss;
+        i++;
+        k++;
+        op = 0;
+      } else if (code == 2u) {
+        H -= gap;
+        i++;
+        op = 1;
+      } else if (code == 1u) {
+        H -= gap;
+        k++;
+        op = 2;
+      } else {
+        broken = true;  // (code 0 with H > 0 cannot happen: every cell on the path had a winning candidate)
+        break;
+      }
+      ops[n++] = (uint8_t)op;
+      if (H <= 0 || n >= cap || i > r0 || k > c0) break;  // done, or off the top / left edge
+    }
+    x = r0 + 1 - i;
+    j = c0 + 1 - k;
   }
   W.outs[P.pair].nops = n;
 }

@@ -11,6 +11,7 @@
 #include <array>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -282,7 +283,7 @@ namespace {
 // One submission of pairs [begin, end), in two halves so that a driver can keep two in flight (a work package:
 // the next sub-batch is staged and queued while this one is on the GPU).  Caller holds the context mutex.
 struct ChunkJob {
-  size_t begin = 0, n = 0, out_ops = 0, ops_bytes = 0, arena_base = 0;
+  size_t begin = 0, n = 0, out_ops = 0, ops_bytes = 0, arena_base = 0, err_at = 0;
   bool want_trace = false, one_copy = false, full_copy = false;
   uint8_t* d_out = nullptr;
   const PairSpec* specs = nullptr;
@@ -499,6 +500,12 @@ int exact_chunk_begin(Context& c, Workspace& ws, const PairSpec* specs, size_t b
   w.err = (uint32_t*)d_zero + 32;
   w.pair_done = (uint32_t*)d_zero + 64;
   w.recs = (ExactRec*)ws.xrecs.p;
+  {  // (read at every submission, so that a test can switch them; defaults: 4 s, off)
+    const char* ms = getenv("SW_HIP_EXACT_WAIT_MS");
+    w.wait_ticks = (unsigned long long)(ms && atoll(ms) > 0 ? atoll(ms) : 4000) * 100000ull;
+    const char* drop = getenv("SW_HIP_DEBUG_DROP_HANDOVER");
+    w.debug_drop = drop && atoi(drop) ? 1u : 0u;
+  }
   HIPCK(launch_exact(w, sc, c.stream));
   if (want_trace) HIPCK(launch_walk(w.pairs, w.outs, (uint32_t)n, rpl, sc, c.stream));
   HIPCK(hipEventRecord(ws.ev_k1, c.stream));
@@ -507,8 +514,11 @@ int exact_chunk_begin(Context& c, Workspace& ws, const PairSpec* specs, size_t b
   full_copy = full_copy && want_trace && ops_bytes;
   const bool one_copy = !full_copy && want_trace && out_bytes <= ((size_t)4 << 20);
   const size_t first_bytes = one_copy ? out_bytes : n * sizeof(ExactOut);
-  if ((rc = ws.h_out.ensure(first_bytes))) return rc;
+  const size_t err_at = (first_bytes + 15) & ~(size_t)15;  // the kernels' error word travels with the results
+  if ((rc = ws.h_out.ensure(err_at + 16))) return rc;
   HIPCK(hipMemcpyAsync(ws.h_out.p, d_out, first_bytes, hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipMemcpyAsync((uint8_t*)ws.h_out.p + err_at, w.err, 4, hipMemcpyDeviceToHost, c.stream));
+  job.err_at = err_at;
   if (full_copy) {  // (the arena is page-locked memory: the copy lands in place)
     job.arena_base = arena->size();
     arena->resize(job.arena_base + ops_bytes);
@@ -543,6 +553,10 @@ int exact_chunk_end(Context& c, Workspace& ws, ChunkJob& job, PairOut* outs) {
   auto& hp = ws.xh.hp;
   const ExactOut* ho = (const ExactOut*)ws.h_out.p;
   tm.lap("  chunk: gpu");
+  // a hand-over wait ran out: the waiting waves ended without results (sw_exact.hip), nothing of this submission
+  // may be used
+  if (*(const uint32_t*)((const uint8_t*)ws.h_out.p + job.err_at) != 0)
+    return fail(SW_E_HIP, "exact kernel: strip pipeline wait timed out");
   for (size_t i = 0; i < n; i++)
     if (ho[i].nops == 0xffffffffu) return fail(SW_E_HIP, "exact kernel: strip pipeline wait timed out");
   float ms = 0;
@@ -1087,10 +1101,14 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
   std::vector<size_t> lens(n_distinct, 0);
   size_t total_bytes = 0;
   std::vector<size_t> sym_at(n_distinct, 0);
+  parallel_ranges(n_distinct, n_distinct * 256, [&](size_t lo, size_t hi) {  // (a package of reads: 10^5 strlen calls)
+    for (size_t d = lo; d < hi; d++)
+      if (used[d] && distinct_p[d]) lens[d] = strlen(distinct_p[d]);
+  });
   for (size_t d = 0; d < n_distinct; d++)
     if (used[d] && distinct_p[d]) {
       sym_at[d] = total_bytes;
-      total_bytes += (lens[d] = strlen(distinct_p[d]));
+      total_bytes += lens[d];
     }
   // one pool for the symbols of all sequences (a sequence has at most as many symbols as bytes)
   std::vector<uint16_t, NoInitAlloc<uint16_t>> sym_pool(total_bytes + 1);
@@ -1100,16 +1118,30 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
       ok[d] = used[d] && distinct_p[d] && decode(distinct_p[d], lens[d], dec[d]) && dec[d].sym.size() < 0x7fffff00u;
   });
   tm.lap("decode");
-  std::vector<PairSpec> specs;
-  std::vector<size_t> idx;
-  specs.reserve(n);
-  idx.reserve(n);
-  for (size_t i = 0; i < n; i++) {
-    if (qi[i] == UINT32_MAX || ti[i] == UINT32_MAX || !ok[qi[i]] || !ok[ti[i]]) continue;
-    const Decoded &q = dec[qi[i]], &t = dec[ti[i]];
-    if (ring_div_by_zero(path, (uint32_t)q.sym.size(), (uint32_t)t.sym.size(), sc)) continue;
-    specs.push_back(PairSpec{q.sym.data(), (uint32_t)q.sym.size(), t.sym.data(), (uint32_t)t.sym.size(), path, qi[i], ti[i]});
-    idx.push_back(i);
+  // (filled in place on the host threads; pairs the reference would fail on are squeezed out afterwards -- rare)
+  std::vector<PairSpec> specs(n);
+  std::vector<size_t> idx(n);
+  std::vector<uint8_t> valid(n);
+  parallel_ranges(n, n * 64, [&](size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+      idx[i] = i;
+      valid[i] = 0;
+      if (qi[i] == UINT32_MAX || ti[i] == UINT32_MAX || !ok[qi[i]] || !ok[ti[i]]) continue;
+      const Decoded &q = dec[qi[i]], &t = dec[ti[i]];
+      if (ring_div_by_zero(path, (uint32_t)q.sym.size(), (uint32_t)t.sym.size(), sc)) continue;
+      specs[i] = PairSpec{q.sym.data(), (uint32_t)q.sym.size(), t.sym.data(), (uint32_t)t.sym.size(), path, qi[i], ti[i]};
+      valid[i] = 1;
+    }
+  });
+  {
+    size_t w = 0;
+    for (size_t i = 0; i < n; i++)
+      if (valid[i]) {
+        if (w != i) specs[w] = specs[i], idx[w] = i;
+        w++;
+      }
+    specs.resize(w);
+    idx.resize(w);
   }
   std::vector<PairOut> po(specs.size());
   ArenaLease lease;
@@ -1125,27 +1157,20 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
     if (rc) return rc;
     tm.lap("windows");
   }
-  // Big batches of short pairs: one pair per lane (sw_lanes.hip) instead of one 256-row strip per wave.
-  if (path != SW_PATH_STRAIGHT && !specs.empty()) {
-    std::vector<uint8_t> small(specs.size());
-    for (size_t k = 0; k < specs.size(); k++) small[k] = dec[qi[idx[k]]].ascii && dec[ti[idx[k]]].ascii;
-    const int rc = align_lanes(device, specs.data(), specs.size(), small.data(), sc, po.data(), arena, handled.data());
-    if (rc) return rc;
-    tm.lap("lanes");
-  }
   // Results of pairs [k_lo, k_hi) as ONE slab: [Slab | ResultBox x pairs | per pair: StrHdr + query alignment + NUL,
   // StrHdr + target alignment + NUL].  ASCII pairs (the normal case) know their string lengths up front (= the
   // number of traceback ops); a pair with non-ASCII symbols re-encodes to UTF-8 and keeps heap strings of its own.
-  auto emit = [&](size_t k_lo, size_t k_hi, const OpsArena& ar) -> int {
-    if (k_hi <= k_lo) return SW_OK;
-    const size_t m = k_hi - k_lo;
+  // (ks: the pairs as a list of indices into specs; nullptr: the range [k_lo, k_hi))
+  auto emit_list = [&](const uint32_t* ks, size_t k_lo, size_t m, const OpsArena& ar) -> int {
+    if (m == 0) return SW_OK;
+    auto k_of = [&](size_t kk) -> size_t { return ks ? ks[kk] : k_lo + kk; };
     auto round8 = [](size_t v) { return (v + 7) & ~(size_t)7; };
     std::vector<size_t> str_off(m + 1, 0);
     const size_t boxes_off = round8(sizeof(Slab));
     size_t bytes = boxes_off + m * sizeof(ResultBox);
-    for (size_t k = k_lo; k < k_hi; k++) {
-      const size_t i = idx[k];
-      str_off[k - k_lo] = bytes;
+    for (size_t kk = 0; kk < m; kk++) {
+      const size_t k = k_of(kk), i = idx[k];
+      str_off[kk] = bytes;
       if (dec[qi[i]].ascii && dec[ti[i]].ascii) bytes += 2 * (sizeof(StrHdr) + round8((size_t)po[k].nops + 1));
     }
     str_off[m] = bytes;
@@ -1157,7 +1182,7 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
     parallel_ranges(m, ar.size() * 4 + m * 64, [&](size_t lo, size_t hi) {
       uint64_t mine = 0;
       for (size_t kk = lo; kk < hi; kk++) {
-        const size_t k = k_lo + kk, i = idx[k];
+        const size_t k = k_of(kk), i = idx[k];
         ResultBox* b = boxes + kk;
         memset(b, 0, sizeof(ResultBox));
         const Decoded &q = dec[qi[i]], &t = dec[ti[i]];
@@ -1201,6 +1226,81 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
     else slab->refs.store(live.load(), std::memory_order_release);
     return SW_OK;
   };
+  auto emit = [&](size_t k_lo, size_t k_hi, const OpsArena& ar) -> int {
+    return k_hi > k_lo ? emit_list(nullptr, k_lo, k_hi - k_lo, ar) : SW_OK;
+  };
+
+  // Big batches of short pairs: one pair per lane (sw_lanes.hip) instead of one 256-row strip per wave.  The batch
+  // goes to the GPU in slices; the result strings of a finished slice are assembled on a second thread while the
+  // next slice runs (one slab per slice).
+  std::vector<uint8_t> emitted;
+  if (path != SW_PATH_STRAIGHT && !specs.empty()) {
+    std::vector<uint8_t> small(specs.size());
+    for (size_t k = 0; k < specs.size(); k++) small[k] = dec[qi[idx[k]]].ascii && dec[ti[idx[k]]].ascii;
+    struct {
+      std::mutex mu;
+      std::condition_variable cv;
+      std::deque<std::vector<uint32_t>> q;
+      bool done = false;
+      int rc = SW_OK;
+      std::string err;
+    } lq;
+    auto emit_slice = [&](const std::vector<uint32_t>& ks) {
+      if (emitted.empty()) emitted.assign(specs.size(), 0);
+      const int erc = guarded<int>(SW_E_NOMEM, [&] { return emit_list(ks.data(), 0, ks.size(), arena); });
+      if (erc) {
+        std::lock_guard<std::mutex> lk(lq.mu);
+        if (!lq.rc) lq.rc = erc, lq.err = last_error_string();
+      }
+      for (uint32_t k : ks) emitted[k] = 1;
+    };
+    std::thread consumer;
+    bool threaded = false;
+    if (specs.size() >= 32768) {
+      emitted.assign(specs.size(), 0);
+      try {
+        consumer = std::thread([&]() noexcept {
+          for (;;) {
+            std::vector<uint32_t> ks;
+            {
+              std::unique_lock<std::mutex> lk(lq.mu);
+              lq.cv.wait(lk, [&] { return lq.done || !lq.q.empty(); });
+              if (lq.q.empty()) return;
+              ks.swap(lq.q.front());
+              lq.q.pop_front();
+            }
+            emit_slice(ks);
+          }
+        });
+        threaded = true;
+      } catch (...) {
+      }
+    }
+    const LanesReady ready = [&](const uint32_t* ks, size_t m) {
+      if (!threaded) return;  // (the strings are assembled with everything else, below)
+      std::vector<uint32_t> v(ks, ks + m);
+      {
+        std::lock_guard<std::mutex> lk(lq.mu);
+        lq.q.emplace_back(std::move(v));
+      }
+      lq.cv.notify_one();
+    };
+    const int rc = guarded<int>(SW_E_NOMEM, [&] {
+      return align_lanes(device, specs.data(), specs.size(), small.data(), sc, po.data(), arena, handled.data(), ready);
+    });
+    const std::string rc_err = rc ? last_error_string() : std::string();
+    if (threaded) {
+      {
+        std::lock_guard<std::mutex> lk(lq.mu);
+        lq.done = true;
+      }
+      lq.cv.notify_one();
+      consumer.join();
+    }
+    if (rc) return fail(rc, rc_err);
+    if (lq.rc) return fail(lq.rc, lq.err);
+    tm.lap("lanes (+ strings of its slices)");
+  }
 
   size_t n_handled = 0;
   for (uint8_t h_ : handled) n_handled += h_ != 0;
@@ -1321,7 +1421,15 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
     }
   }
   tm.lap("run_exact");
-  const int erc = emit(0, specs.size(), arena);
+  int erc;
+  if (emitted.empty()) {
+    erc = emit(0, specs.size(), arena);
+  } else {  // (the lane kernel's slices have their strings already)
+    std::vector<uint32_t> rest_ks;
+    for (size_t k = 0; k < specs.size(); k++)
+      if (!emitted[k]) rest_ks.push_back((uint32_t)k);
+    erc = emit_list(rest_ks.data(), 0, rest_ks.size(), arena);
+  }
   tm.lap("strings");
   return erc;
 }
