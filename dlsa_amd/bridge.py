@@ -161,6 +161,8 @@ def lib():
                              f"{L.sw_hip_struct_size(which)}: dlsa_amd/bridge.py has fallen behind include/*.h")
     L.sw_hip_package_stats.argtypes = [C.POINTER(C.c_uint64)]
     L.sw_hip_package_stats.restype = None
+    L.sw_hip_set_scratch_mb.argtypes = [C.c_int, C.c_uint64]
+    L.sw_hip_set_scratch_mb.restype = C.c_int
     L.sw_hip_path_params.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
     L.sw_hip_path_params.restype = C.c_int
     L.sw_hip_test_units.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
@@ -558,6 +560,13 @@ def package_stats():
     out = (C.c_uint64 * 7)()
     lib().sw_hip_package_stats(out)
     return dict(zip(("pairs", "queries", "windows", "rounds", "window_cells", "chunks", "chunk_escapes"), [int(x) for x in out]))
+
+
+def set_scratch_mb(mb, device=-1):
+    """sw_hip_set_scratch_mb: the device's scratch budget (exact submissions are cut, work packages sliced by it)."""
+    rc = lib().sw_hip_set_scratch_mb(device, mb)
+    if rc != 0:
+        raise SwHipError(f"sw_hip_set_scratch_mb failed ({rc}): {last_error()}")
 
 
 def last_stats():

@@ -105,7 +105,9 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
   };
   std::vector<Slice> slices;
   {
-    const size_t want = el.size() >= 32768 ? std::min<size_t>(16, std::max<size_t>(2, el.size() / 50000)) : 1;  // (a slice should still fill the GPU: >= 400 waves)
+    // (two slices at least for a batch worth pipelining; beyond that a slice keeps >= 2048 waves so that it still
+    // fills the GPU's 1024 SIMDs twice over)
+    const size_t want = el.size() >= 32768 ? std::min<size_t>(16, std::max<size_t>(2, el.size() / 131072)) : 1;
     const size_t per = (n_groups + want - 1) / want;
     size_t g0 = 0;
     while (g0 < n_groups) {

@@ -1079,9 +1079,19 @@ int swhip::align_many_on(int device, const char* const* queries, const char* con
 int swhip::align_interned(int device, const char* const* distinct_p, size_t n_distinct, const uint32_t* qi,
                           const uint32_t* ti, size_t n, AlignmentScores as, int path, Result** out) {
   if (n == 0) return SW_OK;
-  StageTimer tm(n);
   if (!distinct_p || !qi || !ti || !out) return fail(SW_E_ARG, "null argument");
   if (path < 0 || path > 2) return fail(SW_E_ARG, "bad path");
+  // A package of millions of pairs (C5's 1 000 x 10 000 reads) goes through in parts of 2^19 pairs: host tables,
+  // the page-locked traceback arena and the device scratch stay what half a million pairs need, whatever n is.
+  constexpr size_t kPart = (size_t)1 << 19;
+  if (n > kPart) {
+    for (size_t lo = 0; lo < n; lo += kPart) {
+      const int rc = align_interned(device, distinct_p, n_distinct, qi + lo, ti + lo, std::min(kPart, n - lo), as, path, out + lo);
+      if (rc) return rc;  // (the caller frees what earlier parts handed over)
+    }
+    return SW_OK;
+  }
+  StageTimer tm(n);
   const Scoring sc = to_scoring(as);
   // only the sequences some pair names are decoded (a package may carry more)
   std::vector<uint8_t> used(n_distinct, 0);
@@ -1694,6 +1704,14 @@ int sw_hip_path_params(int path, uint64_t q_len, uint64_t t_len, uint32_t out[4]
   out[1] = pp.T0;
   out[2] = pp.phaseQp;
   out[3] = pp.straight;
+  return SW_OK;
+}
+
+int sw_hip_set_scratch_mb(int device, uint64_t mb) {
+  if (mb == 0) return fail(SW_E_ARG, "scratch budget must be positive");
+  CtxLock L(device);
+  if (L.rc) return L.rc;
+  L.c->scratch_budget = (size_t)mb << 20;
   return SW_OK;
 }
 

@@ -21,6 +21,7 @@
 // targets of 10-200 kb).  Everything else takes the whole-matrix path of sw_lib.cpp.
 #include <algorithm>
 #include <cstring>
+#include <cmath>
 #include <map>
 #include <mutex>
 #include <memory>
@@ -138,8 +139,49 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
     by_targets[tids].push_back(kv.first);
   }
   tm0.lap("  windows: target sets");
+  // A set whose boundary ring (one slot per work unit: residues of the chunks x Q / 128 bytes) would not fit twice the
+  // scratch budget is processed in SLICES of its targets, each a temporary database of its own, instead of being
+  // left to the whole-matrix path: the same passes, just more of them.
+  struct SetJob {
+    std::vector<uint32_t> tids;             // sorted
+    const std::vector<uint32_t>* queries;   // of the whole set
+    bool partial;                           // a slice: only the pairs whose target is in tids
+  };
+  std::vector<SetJob> jobs;
   for (auto& set : by_targets) {
-    const std::vector<uint32_t>& tids = set.first;
+    uint64_t residues = 0;
+    uint32_t qmax = 0;
+    for (uint32_t t : set.first) residues += dec[t].sym.size();
+    for (uint32_t qid : set.second) qmax = std::max<uint32_t>(qmax, (uint32_t)dec[qid].sym.size());
+    // (chunks overlap: 1.5 x the residues at the usual stride of 2 O; a slice that still comes out too large is
+    // caught by the exact check against the built database below)
+    const double qpad = (double)roundup64(qmax);
+    const double ring = (double)residues * 1.6 * qpad / 128.0;
+    // (the ring is sized by a bound on the number of units that includes three per persistent workgroup)
+    const double fixed = (3.0 * ctx->cus * score_workgroups_per_cu(16) + 4.0) * qpad * 256.0;
+    const double room = 2.0 * (double)ctx->scratch_budget * 0.85 - fixed;
+    size_t parts = room > 0 ? (size_t)std::min<double>((double)set.first.size(), std::ceil(ring / room)) : 1;
+    if (parts <= 1) {
+      jobs.push_back(SetJob{set.first, &set.second, false});
+      continue;
+    }
+    const uint64_t per = residues / parts + 1;
+    std::vector<uint32_t> cur;
+    uint64_t have = 0;
+    for (uint32_t t : set.first) {
+      cur.push_back(t);
+      have += dec[t].sym.size();
+      if (have >= per) {
+        jobs.push_back(SetJob{std::move(cur), &set.second, true});
+        cur.clear();
+        have = 0;
+      }
+    }
+    if (!cur.empty()) jobs.push_back(SetJob{std::move(cur), &set.second, true});
+  }
+  for (SetJob& job : jobs) {
+    const std::vector<uint32_t>& tids = job.tids;
+    const std::vector<uint32_t>& set_queries = *job.queries;
     struct LapAtExit {  // (declared before the database holder: reports the time of its release too)
       StageTimer& t;
       ~LapAtExit() { t.lap("  windows: set done"); }
@@ -154,7 +196,7 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
     // every decision of the traceback falls the same way (the predecessor that wins is on the path, hence exact;
     // the losers can only be smaller).  Own regions tile the target, so score, first end cell and path are exact.
     uint32_t Qmax = 0;
-    for (uint32_t qid : set.second) Qmax = std::max<uint32_t>(Qmax, (uint32_t)dec[qid].sym.size());
+    for (uint32_t qid : set_queries) Qmax = std::max<uint32_t>(Qmax, (uint32_t)dec[qid].sym.size());
     const uint64_t O = (uint64_t)Qmax + (uint64_t)Qmax * (uint64_t)sc.match / (uint64_t)(-sc.gap) + 1;
     // Chunk stride S: 2 O (half as much overlap as payload) when the set is large; a set with fewer residues gets
     // shorter chunks, down to O / 2, so that there are still about a hundred groups of 128 chunks -- every group is
@@ -232,8 +274,8 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
     auto start = [&](int slot) -> int {
       Flight& F = flights[slot];
       F.active = false;
-      while (next_query < set.second.size()) {
-        const uint32_t qid = set.second[next_query++];
+      while (next_query < set_queries.size()) {
+        const uint32_t qid = set_queries[next_query++];
         const Decoded& q = dec[qid];
         const uint32_t Q = (uint32_t)q.sym.size();
         if (db_persist_ring_bytes(db, Q, L.c->cus) > 2 * L.c->scratch_budget) continue;  // whole-matrix path instead
@@ -261,7 +303,11 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
       const uint32_t qid = flights[cur].qid;
       const Decoded& q = dec[qid];
       const uint32_t Q = (uint32_t)q.sym.size();
-      const std::vector<size_t>& pairs = by_query[qid];
+      std::vector<size_t> pairs_of_slice;
+      if (job.partial)
+        for (size_t k : by_query[qid])
+          if (std::binary_search(tids.begin(), tids.end(), pair_t[k])) pairs_of_slice.push_back(k);
+      const std::vector<size_t>& pairs = job.partial ? pairs_of_slice : by_query[qid];
       if ((rc = db_score_persist_end_locked(*L.c, db, pp))) return rc;
       st.queries++;
       if (tm.on) fprintf(stderr, "[sw_hip]   windows: score kernel %.3f ms (Q = %u)\n", L.c->stats.score_kernel_ms, Q);

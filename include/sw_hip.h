@@ -224,6 +224,13 @@ float sw_node_benchmark_cups(sw_node *node);
  * that share a device do not overwrite each other); a caller adds the shards up. */
 int sw_node_last_stats(const sw_node_db *db, int shard, struct sw_kernel_stats *out);
 
+/* Scratch budget of one device (-1: the default device) in MiB: what one exact submission may take for direction
+ * bits and boundary rows (larger batches are cut), and half of what the score kernel's boundary rings may take
+ * (a work package beyond that is processed in slices of its targets).  Default 8192, or SW_HIP_SCRATCH_MB at the
+ * time the device is first used.  A deployment limit, and the way the tests reach the slicing code with small
+ * inputs. */
+int sw_hip_set_scratch_mb(int device, uint64_t mb);
+
 /* ---- test hook (no GPU needed) ------------------------------------------------------------------------ */
 /* The four integers by which one plain Smith-Waterman reproduces a reference entry point for a pair of
  * lengths (Q, T) (DESIGN.md "Effective semantics"): out[0] = last column computed for rows x >= 2,

@@ -141,6 +141,38 @@ def work_case(name, qlen, lens, nq=1):
     print(json.dumps({"case": name, "pairs": n, "cells": cells, "call_ms": round(best * 1e3, 2), "free_ms": round(bestf * 1e3, 2),
                       "gcups_incl_free": round(cells / (best + bestf) / 1e9, 1), "check": chk}), flush=True)
 
+def work_big_case(name, nq, nt, L):
+    """SURVEY.md 8d's scaled C5 end-to-end run: nq x nt reads of L nt, EVERY pair through sw_execute_work (one record with
+    both aligned strings per pair, as an unmodified master wants them)."""
+    import ctypes as C, resource
+    fq, oq = bridge.synth(201, nq, L, L)
+    ft, ot = bridge.synth(202, nt, L, L)
+    seqs = [fq[int(oq[i]):int(oq[i + 1])].tobytes() for i in range(nq)] + [ft[int(ot[i]):int(ot[i + 1])].tobytes() for i in range(nt)]
+    Lb = bridge.lib()
+    arr = (C.c_char_p * len(seqs))(*seqs)
+    n = nq * nt
+    pr = np.empty((n, 2), dtype=np.uint32)
+    pr[:, 0] = np.repeat(np.arange(nq, dtype=np.uint32), nt)
+    pr[:, 1] = np.tile(np.arange(nq, nq + nt, dtype=np.uint32), nq)
+    pairs = pr.ctypes.data_as(C.POINTER(bridge.CWorkPair))
+    pkg = bridge.CWorkPackage(arr, len(seqs), pairs, n, 2, 1, 1)
+    out = (bridge.CAlignmentDetail * n)()
+    best = bestf = 1e9
+    for _ in range(2):
+        k0 = bridge.last_stats()
+        t0 = time.perf_counter(); rc = Lb.sw_execute_work(C.byref(pkg), out); dt = time.perf_counter() - t0
+        assert rc >= 0, bridge.last_error()
+        st = bridge.last_stats()
+        chk = sum(int(out[i].score) for i in range(0, n, max(1, n // 97)))
+        t1 = time.perf_counter(); Lb.sw_alignment_details_free(out, n); tf = time.perf_counter() - t1
+        best = min(best, dt); bestf = min(bestf, tf)
+    cells = float(L) * L * n
+    print(json.dumps({"case": name, "pairs": n, "cells": cells, "call_s": round(best, 3), "free_s": round(bestf, 3),
+                      "pairs_per_s": round(n / best), "gcups_call": round(cells / best / 1e9, 1),
+                      "lanes_kernel_ms_last_part": round(st["lanes_kernel_ms"], 2), "lanes_pairs_last_part": st["lanes_pairs"],
+                      "peak_rss_gb": round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 2), "check": chk}), flush=True)
+
+
 which = sys.argv[1:]
 rng = np.random.default_rng(3)
 if "c1" in which: db_case("C1 1kb x 1000x[900,1100]", 1000, rng.integers(900, 1101, size=1000))
@@ -172,4 +204,6 @@ if "strips" in which:
 if "b3" in which: package_case("ExecuteWork generate_synthetic_data defaults: 10 x [200,1000] vs 800 x [10k,200k]", 10, 200, 1000, 800, 10000, 200000)
 if "b3s" in which: package_case("ExecuteWork 10 x [200,1000] vs 100 x [10k,200k]", 10, 200, 1000, 100, 10000, 200000)
 if "w2" in which: work_case("sw_execute_work 8 x 1000 pairs of ~1kb", 1000, rng.integers(900, 1101, size=1000), nq=8)
+if "w5e" in which: work_big_case("sw_execute_work scaled C5 e2e: 1000 x 10000 reads of 150 nt, every pair", 1000, 10000, 150)
+if "w5m" in which: work_big_case("sw_execute_work 100 x 10000 reads of 150 nt, every pair", 100, 10000, 150)
 if "w5" in which: work_case("sw_execute_work 150 x 100000x150", 150, np.full(100000, 150))

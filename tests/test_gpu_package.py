@@ -90,3 +90,37 @@ def test_package_mixed_with_ineligible_pairs_and_other_scorings(oracle):
         a = d.alignment
         assert (a.query_alignment, a.target_alignment, a.score, a.maxX, a.maxY, a.length) == (
             e["q"], e["t"], e["score"], e["max_x"], e["max_y"], len(e["q"]))
+
+
+def test_package_beyond_the_ring_budget_is_sliced_not_dropped(oracle):
+    """A target set whose boundary ring would not fit twice the scratch budget is processed in slices of its targets
+    (sw_package.cpp), not left to the whole-matrix path.  52 M residues against a 480-nt query want ~330 MB of ring;
+    with the budget at 160 MiB the set goes through in two slices: still the fast path (chunks > 0, every pair
+    answered by it, more score passes than queries), results equal to the unsliced run's and to the oracle's."""
+    import dlsa_amd
+    from dlsa_amd import bridge
+    rng = random.Random(47)
+    nrng = np.random.default_rng(47)
+    s = dlsa_amd.AlignmentScore(SC[1], SC[2], SC[0])
+    queries = [_rnd(rng, 300), _rnd(rng, 480)]
+    lut = np.frombuffer(b"ACGT", dtype=np.uint8)
+    targets = [lut[nrng.integers(0, 4, size=int(n), dtype=np.uint8)].tobytes().decode() for n in nrng.integers(110000, 150000, size=400)]
+    targets[3] = targets[3][:700] + _mut(rng, queries[1][20:460], 0.05) + targets[3][700:]
+    targets[317] = targets[317][:90000] + queries[0][5:290] + targets[317][90000:]
+    qs = [q for q in queries for _ in targets]
+    ts = targets * len(queries)
+    whole = bridge.align_batch(qs, ts, s, 0)
+    st0 = bridge.package_stats()
+    assert st0["pairs"] == len(qs) and st0["queries"] == len(queries), st0
+    bridge.set_scratch_mb(160)
+    try:
+        res = bridge.align_batch(qs, ts, s, 0)
+        st = bridge.package_stats()
+    finally:
+        bridge.set_scratch_mb(8192)
+    assert st["chunks"] > 0 and st["pairs"] == len(qs), st
+    assert st["queries"] > len(queries), st          # more score passes than queries: the set went through in slices
+    key = lambda r: (r.score, r.max_x, r.max_y, r.query, r.target)  # noqa: E731
+    assert [key(r) for r in res] == [key(r) for r in whole]
+    for i in (3, 317, 400 + 3, 400 + 317, 11, 799):
+        _check(oracle, res[i], qs[i], ts[i])
