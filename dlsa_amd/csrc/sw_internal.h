@@ -141,11 +141,18 @@ struct LanePair {       // lane l of group g: lanes[g * 64 + l]
   uint32_t pad_;
   uint64_t ops_off;     // traceback ops of this pair in LanesWork::ops (capacity Q + T)
 };
-struct LaneGroup {      // 64 pairs, one wave
-  uint32_t Qmax;        // rows the wave runs: max Q of its lanes, rounded up to 8
+struct LaneGroup {      // 64 pairs: one wave per 16-column strip
+  uint32_t Qmax;        // rows a wave runs: max Q of the group's lanes, rounded up to 8
   uint32_t nstrips;     // 16-column strips: ceil(max T / 16)
   uint64_t dirs_off;    // dwords: direction words of the group, [strip][row][lane]
-  uint64_t hb_off;      // dwords: boundary column between strips, [row][lane], rewritten in place by every strip
+  uint64_t hb_off;      // dwords: boundary column between strips, [row][lane], rewritten in place by every strip;
+                        // a word is H << 16 | (strip that wrote it + 1); zeroed before the launch
+  uint32_t rec_off;     // first of the group's nstrips x 64 best-cell records (LanesWork::recs)
+  uint32_t pad_;
+};
+struct LaneRec {        // best cell of one lane within one strip
+  uint32_t score;
+  uint32_t key;         // (x + j) << 16 | x, 1-based (0xffffffff: none)
 };
 struct LaneOut {
   int32_t score;        // H of the best cell (0: no hit)
@@ -160,7 +167,13 @@ struct LanesWork {
   uint32_t* hb;
   uint8_t* ops;
   LaneOut* outs;
+  LaneRec* recs;
+  const uint32_t* units;  // per ticket: strip << 20 | group, strip level by level (a strip's left neighbour first)
+  uint32_t* ticket;       // work counter (zeroed)
+  uint32_t* err;          // != 0: a hand-over wait timed out (zeroed); the waiting waves have ended, results are void
+  unsigned long long wait_ticks;  // budget of a hand-over wait in s_memrealtime ticks (100 MHz)
   uint32_t n_groups;
+  uint32_t n_units;       // sum of the groups' strips
 };
 hipError_t launch_lanes(const LanesWork& w, Scoring sc, bool want_trace, hipStream_t stream);
 

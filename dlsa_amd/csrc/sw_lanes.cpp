@@ -80,9 +80,13 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
     padded_cells += (uint64_t)groups[g].Qmax * groups[g].nstrips * 16 * 64;
   }
   if (mode == 2) {
-    // a wave alone on its SIMD issues at about half rate; 1024 SIMDs share the sum
-    const double lanes_ns = std::max(cyc_max / 0.5, cyc_sum / 1024 / 0.75) / 2.4;
-    if (el.size() < 4096 || lanes_ns > 0.8 * wave_ns) return SW_OK;
+    // Every strip of a group is a wave of its own: the waves share 1024 SIMDs (about 0.7 of the issue rate is
+    // reached), and a group is done no sooner than its pipeline of strips -- the rows of one strip plus about 24 rows
+    // of lag per further strip, on waves that may be alone on their SIMD (half rate).
+    double crit = 0;
+    for (const LaneGroup& g : groups) crit = std::max(crit, ((double)g.Qmax + 24.0 * g.nstrips) * 16 * 30.0);
+    const double lanes_ns = std::max(crit / 0.5, cyc_sum / 1024 / 0.7) / 2.4;
+    if (el.size() < 1024 || lanes_ns > 0.8 * wave_ns) return SW_OK;
   }
   tm.lap("lanes: eligible + sort");
 
@@ -99,7 +103,7 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
   // i + 1 is staged and queued behind it on the second workspace, and the caller's `ready` (string assembly, on
   // another thread) works on slice i - 1.
   struct Slice {
-    size_t g0 = 0, g1 = 0, dir_words = 0, hb_words = 0, ops_base = 0, ops_bytes = 0;
+    size_t g0 = 0, g1 = 0, dir_words = 0, hb_words = 0, ops_base = 0, ops_bytes = 0, n_units = 0;
     std::vector<LanePair> lanes;
     uint64_t cells = 0;
   };
@@ -114,11 +118,13 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
       Slice sl;
       sl.g0 = g0;
       size_t g1 = g0;
-      while (g1 < n_groups && g1 - g0 < per) {
+      while (g1 < n_groups && g1 - g0 < per && g1 - g0 < 0xfffffu && sl.n_units < 0x7ff00000u) {
         const size_t dw = (size_t)groups[g1].Qmax * groups[g1].nstrips * 64, hw = (size_t)groups[g1].Qmax * 64;
         if (g1 > g0 && (sl.dir_words + dw + sl.hb_words + hw) * 4 > c.scratch_budget / 2) break;
         groups[g1].dirs_off = sl.dir_words;
         groups[g1].hb_off = sl.hb_words;
+        groups[g1].rec_off = (uint32_t)sl.n_units;
+        sl.n_units += groups[g1].nstrips;
         sl.dir_words += dw;
         sl.hb_words += hw;
         g1++;
@@ -141,7 +147,7 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
   tm.lap("lanes: slices");
 
   struct InFlight {
-    size_t np = 0;
+    size_t np = 0, err_at = 0;
   } fl[2];
   auto align64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
   // stages slice `si` and queues it (copies in, kernels, copies out) on workspace `ws`; does not wait
@@ -190,17 +196,29 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
     }
     sl.ops_bytes = ops_bytes;
     pool_syms += 64;  // (the kernel loads 32 bytes at a sequence's last 16-symbol boundary)
-    const size_t in_groups = 0, in_lanes = align64(ng * sizeof(LaneGroup)), in_pool = in_lanes + align64(sl.lanes.size() * sizeof(LanePair));
+    const size_t in_groups = 0, in_lanes = align64(ng * sizeof(LaneGroup)), in_units = in_lanes + align64(sl.lanes.size() * sizeof(LanePair)),
+                 in_pool = in_units + align64(sl.n_units * 4);
     const size_t in_bytes = in_pool + align64(pool_syms * 2);
+    constexpr size_t kCtl = 256;  // control words in front of the boundary columns: [0] ticket, [32] error word
     const size_t out_ops = align64(np * sizeof(LaneOut)), out_bytes = out_ops + align64(ops_bytes);
     int erc;
     if ((erc = ws.xin.ensure(in_bytes))) return erc;
     if ((erc = ws.h_in.ensure(in_bytes))) return erc;
     if ((erc = ws.dirs.ensure(std::max<size_t>(sl.dir_words * 4, 16)))) return erc;
-    if ((erc = ws.xzero.ensure(std::max<size_t>(sl.hb_words * 4, 16)))) return erc;
+    if ((erc = ws.xzero.ensure(kCtl + sl.hb_words * 4))) return erc;
+    if ((erc = ws.xrecs.ensure(std::max<size_t>(sl.n_units * 64 * sizeof(LaneRec), 16)))) return erc;
     if ((erc = ws.xout.ensure(out_bytes))) return erc;
-    if ((erc = ws.h_out.ensure(out_ops))) return erc;
+    if ((erc = ws.h_out.ensure(out_ops + 16))) return erc;
     uint8_t* const h_in = (uint8_t*)ws.h_in.p;
+    {  // tickets strip level by level: a strip's left neighbour always holds an earlier ticket
+      uint32_t* units = (uint32_t*)(h_in + in_units);
+      uint32_t max_strips = 0;
+      for (size_t g = sl.g0; g < sl.g1; g++) max_strips = std::max(max_strips, groups[g].nstrips);
+      size_t u = 0;
+      for (uint32_t st = 0; st < max_strips; st++)
+        for (size_t g = sl.g0; g < sl.g1; g++)
+          if (groups[g].nstrips > st) units[u++] = (st << 20) | (uint32_t)(g - sl.g0);
+    }
     memcpy(h_in + in_groups, groups.data() + sl.g0, ng * sizeof(LaneGroup));
     memcpy(h_in + in_lanes, sl.lanes.data(), sl.lanes.size() * sizeof(LanePair));
     uint16_t* const hpool = (uint16_t*)(h_in + in_pool);
@@ -213,19 +231,32 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
     });
     memset(hpool + pool_syms - 64, 0xff, 128);
     HIPCK(hipMemcpyAsync(ws.xin.p, h_in, in_bytes, hipMemcpyHostToDevice, c.stream));
+    // (a word of a boundary column is "published" by the tag in its low half, so the columns start at zero)
+    HIPCK(hipMemsetAsync(ws.xzero.p, 0, kCtl + sl.hb_words * 4, c.stream));
     HIPCK(hipEventRecord(ws.ev_k0, c.stream));
     LanesWork w{};
     w.groups = (const LaneGroup*)((uint8_t*)ws.xin.p + in_groups);
     w.lanes = (const LanePair*)((uint8_t*)ws.xin.p + in_lanes);
     w.pool = (const uint16_t*)((uint8_t*)ws.xin.p + in_pool);
     w.dirs = (uint32_t*)ws.dirs.p;
-    w.hb = (uint32_t*)ws.xzero.p;
+    w.hb = (uint32_t*)((uint8_t*)ws.xzero.p + kCtl);
+    w.recs = (LaneRec*)ws.xrecs.p;
+    w.units = (const uint32_t*)((uint8_t*)ws.xin.p + in_units);
+    w.ticket = (uint32_t*)ws.xzero.p;
+    w.err = (uint32_t*)ws.xzero.p + 32;
+    {
+      const char* ms = getenv("SW_HIP_EXACT_WAIT_MS");
+      w.wait_ticks = (unsigned long long)(ms && atoll(ms) > 0 ? atoll(ms) : 4000) * 100000ull;
+    }
+    w.n_units = (uint32_t)sl.n_units;
     w.ops = (uint8_t*)ws.xout.p + out_ops;
     w.outs = (LaneOut*)ws.xout.p;
     w.n_groups = (uint32_t)ng;
     HIPCK(launch_lanes(w, sc, true, c.stream));
     HIPCK(hipEventRecord(ws.ev_k1, c.stream));
     HIPCK(hipMemcpyAsync(ws.h_out.p, ws.xout.p, np * sizeof(LaneOut), hipMemcpyDeviceToHost, c.stream));
+    HIPCK(hipMemcpyAsync((uint8_t*)ws.h_out.p + out_ops, w.err, 4, hipMemcpyDeviceToHost, c.stream));
+    f.err_at = out_ops;
     if (ops_bytes)
       HIPCK(hipMemcpyAsync(arena.data() + arena_base + sl.ops_base, (uint8_t*)ws.xout.p + out_ops, ops_bytes, hipMemcpyDeviceToHost, c.stream));
     HIPCK(hipEventRecord(ws.ev_done, c.stream));
@@ -237,6 +268,8 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
     Slice& sl = slices[si];
     const size_t p0 = sl.g0 * 64, p1 = p0 + f.np;
     HIPCK(hipEventSynchronize(ws.ev_done));
+    if (*(const uint32_t*)((const uint8_t*)ws.h_out.p + f.err_at) != 0)
+      return fail(SW_E_HIP, "lane kernel: strip pipeline wait timed out");
     float ms = 0;
     HIPCK(hipEventElapsedTime(&ms, ws.ev_k0, ws.ev_k1));
     c.stats.exact_kernel_ms += ms;

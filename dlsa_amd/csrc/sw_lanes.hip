@@ -8,9 +8,14 @@
 //
 // Formulation (inter-task, like the score kernel, but exact and with a traceback): a wave holds 64 PAIRS, one per
 // lane, length-sorted by the host so that the lanes of a wave finish together.  A lane keeps a strip of 16 target
-// columns of its own matrix in registers and walks down its query; the strip's right-hand H column goes to the next
-// strip through one dword per row in HBM ([row][lane], coalesced, in place).  No lane ever talks to another lane:
-// no DPP, no skew, no flags, no polling, nothing that could wait.
+// columns of its own matrix in registers and walks down its query.  No lane ever talks to another lane: no DPP, no
+// skew.  The 16-column STRIPS of a group are waves of their own (one wave per group and strip, tickets strip level
+// by level), so that a few thousand pairs already fill the GPU: strip s + 1 takes the right-hand H column of strip
+// s through one dword per row in HBM ([row][lane], coalesced, rewritten in place by every strip).  The low half of
+// such a word is free and carries the number of the strip that wrote it, so a word is its own "published" flag
+// (a dword store is atomic; the column is zeroed before the launch): the consumer prefetches the 8 rows of its next
+// block while it computes the current one and re-polls only rows whose tag is still the previous strip's.  With
+// more groups than resident waves the producer finished long ago and nothing ever waits.
 //
 // Arithmetic (int32, exact on the domain the host admits: min(Q, T) x match <= 32767, Q + T < 65535): a value is
 //   V = H << 16 | tag.  The three candidates of a cell carry tag 3 (diagonal), 2 (up), 1 (left) in their low bits,
@@ -81,11 +86,19 @@ __device__ __forceinline__ void lane_row(uint32_t q, const uint32_t (&t)[16], ui
 
 }  // namespace
 
-// One wave per group of 64 pairs.
+// One wave per (group of 64 pairs, 16-column strip).  Tickets are drawn when a wave starts, strip level by level
+// (LanesWork::units), so the wave of the strip to my left holds an earlier ticket: it is resident or has finished,
+// whatever the dispatch order, and the pipeline of strips cannot deadlock.  A wait that never ends (a bug, not a legal
+// state) is bounded in time, stores the error word and ends the wave; every other waiting wave sees the word and
+// ends too (same containment as sw_exact.hip).
 __global__ void __launch_bounds__(64) sw_lanes_kernel(LanesWork W, int match, int miss, int gap) {
   const uint32_t lane = threadIdx.x;
-  const uint32_t g = blockIdx.x;
-  if (g >= W.n_groups) return;
+  uint32_t tk = 0;
+  if (lane == 0) tk = atomicAdd(W.ticket, 1u);
+  const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+  if (ticket >= W.n_units) return;
+  const uint32_t unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.units[ticket]);
+  const uint32_t g = unit & 0xfffffu, s = unit >> 20;
   const LaneGroup G = W.groups[g];
   const LanePair P = W.lanes[(size_t)g * 64 + lane];
   const gptr<const uint16_t> pool = (gptr<const uint16_t>)W.pool;
@@ -98,77 +111,115 @@ __global__ void __launch_bounds__(64) sw_lanes_kernel(LanesWork W, int match, in
   K.lsub = ((uint32_t)(-gap) << 16) - 1u;
   K.usub = ((uint32_t)(-gap) << 16) - 2u;
   const uint32_t nblk = G.Qmax / 8;  // (Qmax is a multiple of 8)
+#ifndef SW_LANES_TIMING_NO_WAIT
+  const uint32_t tag_in = s, tag_out = s + 1;
+#else  // (timing experiment: every tag reads as published -- results are garbage)
+  const uint32_t tag_in = 0, tag_out = 0;
+#endif  // a word of the boundary column carries the strip that wrote it, + 1
+  const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + W.wait_ticks;
 
-  uint32_t bestH = 0, bestkey = 0xffffffffu;  // key = (x + j) << 16 | x, 1-based
-  for (uint32_t s = 0; s < G.nstrips; s++) {
-    // the strip's 16 target symbols
-    uint32_t t[16];
-    {
-      u4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
-      if (s * 16 < T) {
-        const gptr<const u4> tp = (gptr<const u4>)(pool + P.toff + s * 16);
-        a = tp[0];
-        b = tp[1];
-      }
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        const uint32_t v = c < 8 ? sym8(a, c) : sym8(b, c - 8);
-        t[c] = (s * 16 + (uint32_t)c < T) ? v : kSentT;
-      }
+  // the strip's 16 target symbols
+  uint32_t t[16];
+  {
+    u4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+    if (s * 16 < T) {
+      const gptr<const u4> tp = (gptr<const u4>)(pool + P.toff + s * 16);
+      a = tp[0];
+      b = tp[1];
     }
-    uint32_t H[16], colkey[16];
-#pragma unroll
-    for (int c = 0; c < 16; c++) H[c] = 0, colkey[c] = 0;
-    uint32_t hdiag = 0;  // H(r - 1, first column - 1)
-    // boundary column and query symbols of the first block
-    uint32_t hbn[8];
-    u4 qn = {0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < 8; i++) hbn[i] = s ? hb[(size_t)i * 64] : 0u;
-    if (0 < Q) qn = *(gptr<const u4>)(pool + P.qoff);
-    for (uint32_t rb = 0; rb < nblk; rb++) {
-      uint32_t hbc[8];
-#pragma unroll
-      for (int i = 0; i < 8; i++) hbc[i] = hbn[i];
-      const u4 qc = qn;
-      if (rb + 1 < nblk) {  // next block's inputs, in flight while this one is computed
-        if (s) {
-#pragma unroll
-          for (int i = 0; i < 8; i++) hbn[i] = hb[(size_t)((rb + 1) * 8 + i) * 64];
-        }
-        if ((rb + 1) * 8 < Q) qn = *(gptr<const u4>)(pool + P.qoff + (rb + 1) * 8);
-      }
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const uint32_t r = rb * 8 + (uint32_t)i;
-        const uint32_t q = r < Q ? sym8(qc, i) : kSentQ;
-        uint32_t acc = 0, hright;
-        lane_row(q, t, H, colkey, hbc[i], hdiag, 0xffffu - r, K, acc, hright);
-        hdiag = hbc[i];
-        dirs[((size_t)s * G.Qmax + r) * 64] = acc;
-        hb[(size_t)r * 64] = hright;
-      }
-    }
-    // fold the strip's column records into the lane's best cell
 #pragma unroll
     for (int c = 0; c < 16; c++) {
-      const uint32_t v = colkey[c] >> 16;
-      const uint32_t x = 0x10000u - (colkey[c] & 0xffffu);  // row + 1
-      const uint32_t j = s * 16 + (uint32_t)c + 1;
-      const uint32_t key = ((x + j) << 16) | x;
-      const bool better = v > bestH || (v == bestH && v > 0 && key < bestkey);
-      bestH = better ? v : bestH;
-      bestkey = better ? key : bestkey;
+      const uint32_t v = c < 8 ? sym8(a, c) : sym8(b, c - 8);
+      t[c] = (s * 16 + (uint32_t)c < T) ? v : kSentT;
     }
   }
-  if (Q) {
-    LaneOut o;
-    o.score = (int32_t)bestH;
-    o.bx = bestH ? (bestkey & 0xffffu) : 0;
-    o.bj = bestH ? ((bestkey >> 16) - (bestkey & 0xffffu)) : 0;
-    o.nops = 0;
-    W.outs[P.pair] = o;
+  uint32_t H[16], colkey[16];
+#pragma unroll
+  for (int c = 0; c < 16; c++) H[c] = 0, colkey[c] = 0;
+  uint32_t hdiag = 0;  // H(r - 1, first column - 1)
+  // device-scope accesses: the producer may sit on another XCD (no coherent L2 between them)
+  auto load_hb = [&](uint32_t r) -> uint32_t {
+    return __hip_atomic_load(hb + (size_t)r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // boundary column and query symbols of the first block
+  uint32_t hbn[8];
+  u4 qn = {0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 8; i++) hbn[i] = s ? load_hb((uint32_t)i) : 0u;
+  if (0 < Q) qn = *(gptr<const u4>)(pool + P.qoff);
+  for (uint32_t rb = 0; rb < nblk; rb++) {
+    if (s) {
+      // Every row of this block must come from the strip to my left; normally it does (fetched a block ago).  The
+      // re-poll is a slow path of its own that ends with nothing of its own in flight, so that the fast path carries
+      // no wait for it: a wait after the merge would also wait for the previous block's 16 stores.
+      auto stale = [&]() -> bool {
+        uint32_t bad = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) bad |= hbn[i] ^ tag_in;
+        return __builtin_amdgcn_ballot_w64((bad & 0xffffu) != 0) != 0;
+      };
+      if (stale()) {
+        for (uint32_t spin = 0;; spin++) {
+          if ((spin & 63u) == 63u) {  // (both conditions wave-uniform: s_endpgm must sit behind a scalar branch)
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(W.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            const bool late = __builtin_amdgcn_s_memrealtime() >= deadline;
+            if (e != 0 || late) {
+              if (e == 0) __hip_atomic_store(W.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              asm volatile("s_endpgm" ::: "memory");
+            }
+          }
+          __builtin_amdgcn_s_sleep(2);
+#pragma unroll
+          for (int i = 0; i < 8; i++)
+            if ((hbn[i] ^ tag_in) & 0xffffu) hbn[i] = load_hb(rb * 8 + (uint32_t)i);
+          __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loads above (and everything older) have landed
+          if (!stale()) break;
+        }
+      }
+    }
+    uint32_t hbc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) hbc[i] = hbn[i] & 0xffff0000u;
+    const u4 qc = qn;
+    if (rb + 1 < nblk) {  // next block's inputs, in flight while this one is computed
+      if (s) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) hbn[i] = load_hb((rb + 1) * 8 + (uint32_t)i);
+      }
+      if ((rb + 1) * 8 < Q) qn = *(gptr<const u4>)(pool + P.qoff + (rb + 1) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const uint32_t r = rb * 8 + (uint32_t)i;
+      const uint32_t q = r < Q ? sym8(qc, i) : kSentQ;
+      uint32_t acc = 0, hright;
+      lane_row(q, t, H, colkey, hbc[i], hdiag, 0xffffu - r, K, acc, hright);
+      hdiag = hbc[i];
+#ifndef SW_LANES_TIMING_NO_DIRS  // (timing experiments only: scratch/lanes_variants.sh)
+      dirs[((size_t)s * G.Qmax + r) * 64] = acc;
+#else
+      if (acc == 0x12345678u && hright == 77u) dirs[0] = acc;
+#endif
+      // (the last strip stores too: a test here makes the compiler split the row loop and costs 80 registers)
+      __hip_atomic_store(hb + (size_t)r * 64, hright | tag_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+  // fold the strip's column records into the lane's best cell of this strip; the walker combines the strips
+  uint32_t bestH = 0, bestkey = 0xffffffffu;  // key = (x + j) << 16 | x, 1-based
+#pragma unroll
+  for (int c = 0; c < 16; c++) {
+    const uint32_t v = colkey[c] >> 16;
+    const uint32_t x = 0x10000u - (colkey[c] & 0xffffu);  // row + 1
+    const uint32_t j = s * 16 + (uint32_t)c + 1;
+    const uint32_t key = ((x + j) << 16) | x;
+    const bool better = v > bestH || (v == bestH && v > 0 && key < bestkey);
+    bestH = better ? v : bestH;
+    bestkey = better ? key : bestkey;
+  }
+  LaneRec rec;
+  rec.score = bestH;
+  rec.key = bestkey;
+  W.recs[((size_t)G.rec_off + s) * 64 + lane] = rec;
 }
 
 // Traceback: one LANE per pair follows the direction bits from the best cell until H reaches 0
@@ -185,7 +236,21 @@ __global__ void __launch_bounds__(64) sw_lanes_walk_kernel(LanesWork W, int matc
   const gptr<const uint16_t> pool = (gptr<const uint16_t>)W.pool;
   const gptr<const uint32_t> dirs = (gptr<const uint32_t>)W.dirs + G.dirs_off + lane;
   const gptr<uint8_t> ops = (gptr<uint8_t>)W.ops + P.ops_off;
-  LaneOut o = W.outs[P.pair];
+  // the pair's best cell: largest H, then the reference's discovery order (smallest x + j, then smallest x)
+  uint32_t bestH = 0, bestkey = 0xffffffffu;
+  for (uint32_t s = 0; s < G.nstrips; s++) {
+    const LaneRec r = W.recs[((size_t)G.rec_off + s) * 64 + lane];
+    const bool better = r.score > bestH || (r.score == bestH && r.score > 0 && r.key < bestkey);
+    bestH = better ? r.score : bestH;
+    bestkey = better ? r.key : bestkey;
+  }
+#ifdef SW_LANES_TIMING_NO_WAIT  // (timing experiment: the fill computed garbage, nothing may be walked)
+  bestH = 0;
+#endif
+  LaneOut o;
+  o.score = (int32_t)bestH;
+  o.bx = bestH ? (bestkey & 0xffffu) : 0;
+  o.bj = bestH ? ((bestkey >> 16) - (bestkey & 0xffffu)) : 0;
   int H = o.score;
   uint32_t x = o.bx, j = o.bj, n = 0;
   const uint32_t cap = P.Q + P.T;
@@ -235,14 +300,16 @@ __global__ void __launch_bounds__(64) sw_lanes_walk_kernel(LanesWork W, int matc
     x = r0 + 1 - i;
     j = c0 + 1 - k;
   }
-  W.outs[P.pair].nops = n;
+  o.nops = n;
+  W.outs[P.pair] = o;
 }
 
 hipError_t launch_lanes(const LanesWork& w, Scoring sc, bool want_trace, hipStream_t stream) {
-  if (w.n_groups == 0) return hipSuccess;
-  hipLaunchKernelGGL(sw_lanes_kernel, dim3(w.n_groups), dim3(64), 0, stream, w, sc.match, sc.miss, sc.gap);
+  if (w.n_groups == 0 || w.n_units == 0) return hipSuccess;
+  hipLaunchKernelGGL(sw_lanes_kernel, dim3(w.n_units), dim3(64), 0, stream, w, sc.match, sc.miss, sc.gap);
   hipError_t e = hipGetLastError();
-  if (e != hipSuccess || !want_trace) return e;
+  if (e != hipSuccess) return e;
+  (void)want_trace;  // (the walker also combines the strips' best cells: it always runs)
   hipLaunchKernelGGL(sw_lanes_walk_kernel, dim3(w.n_groups), dim3(64), 0, stream, w, sc.match, sc.miss, sc.gap);
   return hipGetLastError();
 }
