@@ -1325,7 +1325,8 @@ int exact_one_fixed(Context& c, HostArena& arena, const uint16_t* qsym, uint32_t
   if ((rc = ws.xrecs.ensure((size_t)n_units * sizeof(ExactRec)))) return rc;
   unsigned char* h = (unsigned char*)arena.take(in_bytes);
   ExactOut* ho = (ExactOut*)arena.take(sizeof(ExactOut));
-  if (!h || !ho) return fail(SW_E_LIMIT, "sw_db_scores_noalloc: a target that needs the int32 re-run is too long for the host arena");
+  uint32_t* herr = (uint32_t*)arena.take(16);
+  if (!h || !ho || !herr) return fail(SW_E_LIMIT, "sw_db_scores_noalloc: a target that needs the int32 re-run is too long for the host arena");
   unsigned char* const d_in = (unsigned char*)ws.xin.p;
   unsigned char* const d_zero = (unsigned char*)ws.xzero.p;
   ExactPair e{};
@@ -1365,10 +1366,13 @@ int exact_one_fixed(Context& c, HostArena& arena, const uint16_t* qsym, uint32_t
   w.err = (uint32_t*)d_zero + 32;
   w.pair_done = (uint32_t*)d_zero + 64;
   w.recs = (ExactRec*)ws.xrecs.p;
+  w.wait_ticks = exact_wait_ticks();
   HIPCK(launch_exact(w, sc, c.stream));
   HIPCK(hipMemcpyAsync(ho, ws.xout.p, sizeof(ExactOut), hipMemcpyDeviceToHost, c.stream));
+  HIPCK(hipMemcpyAsync(herr, w.err, 4, hipMemcpyDeviceToHost, c.stream));
   HIPCK(hipStreamSynchronize(c.stream));
-  if (ho->nops == 0xffffffffu) return fail(SW_E_HIP, "exact kernel: strip pipeline wait timed out");
+  // (a wave whose hand-over wait ran out has ended without a result: the error word says so)
+  if (*herr != 0 || ho->nops == 0xffffffffu) return fail(SW_E_HIP, "exact kernel: strip pipeline wait timed out");
   *score_out = ho->score;
   c.stats.exact_cells += (uint64_t)Q * T;
   c.stats.rerun_pairs += 1;

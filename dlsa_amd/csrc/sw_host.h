@@ -281,6 +281,7 @@ struct ArenaLease {
   ArenaLease& operator=(const ArenaLease&) = delete;
 };
 PathParams resolve_path(int path, uint32_t Q, uint32_t T);
+unsigned long long exact_wait_ticks();
 bool ring_div_by_zero(int path, uint32_t Q, uint32_t T, Scoring sc);
 // Caller holds the context's lock.
 int run_exact(Context& c, Workspace& ws, const PairSpec* specs, size_t n, Scoring sc, bool want_trace, PairOut* outs,

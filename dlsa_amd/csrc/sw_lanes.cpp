@@ -244,10 +244,7 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
     w.units = (const uint32_t*)((uint8_t*)ws.xin.p + in_units);
     w.ticket = (uint32_t*)ws.xzero.p;
     w.err = (uint32_t*)ws.xzero.p + 32;
-    {
-      const char* ms = getenv("SW_HIP_EXACT_WAIT_MS");
-      w.wait_ticks = (unsigned long long)(ms && atoll(ms) > 0 ? atoll(ms) : 4000) * 100000ull;
-    }
+    w.wait_ticks = exact_wait_ticks();
     w.n_units = (uint32_t)sl.n_units;
     w.ops = (uint8_t*)ws.xout.p + out_ops;
     w.outs = (LaneOut*)ws.xout.p;

@@ -258,6 +258,13 @@ void encode_utf8(uint32_t c, std::string& out) {
 
 // ---- the four integers that make one plain SW reproduce a reference entry point ---------------------------
 // DESIGN.md "Effective semantics"; proven equal to the restatement by tests/test_oracle_clean.py.
+// budget of a hand-over wait of the exact kernels in s_memrealtime ticks (100 MHz): 4 s, or SW_HIP_EXACT_WAIT_MS
+// (read at every submission, so that a test can shorten it)
+unsigned long long swhip::exact_wait_ticks() {
+  const char* ms = getenv("SW_HIP_EXACT_WAIT_MS");
+  return (unsigned long long)(ms && atoll(ms) > 0 ? atoll(ms) : 4000) * 100000ull;
+}
+
 PathParams swhip::resolve_path(int path, uint32_t Q, uint32_t T) {
   PathParams pp{T, T, 0, 0};
   if (path == SW_PATH_STRAIGHT) {
@@ -500,9 +507,8 @@ int exact_chunk_begin(Context& c, Workspace& ws, const PairSpec* specs, size_t b
   w.err = (uint32_t*)d_zero + 32;
   w.pair_done = (uint32_t*)d_zero + 64;
   w.recs = (ExactRec*)ws.xrecs.p;
-  {  // (read at every submission, so that a test can switch them; defaults: 4 s, off)
-    const char* ms = getenv("SW_HIP_EXACT_WAIT_MS");
-    w.wait_ticks = (unsigned long long)(ms && atoll(ms) > 0 ? atoll(ms) : 4000) * 100000ull;
+  w.wait_ticks = exact_wait_ticks();
+  {  // (test hook, read at every submission)
     const char* drop = getenv("SW_HIP_DEBUG_DROP_HANDOVER");
     w.debug_drop = drop && atoi(drop) ? 1u : 0u;
   }
