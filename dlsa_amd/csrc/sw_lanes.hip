@@ -37,6 +37,8 @@
 // Cells outside a lane's matrix (rows >= Q, columns >= T of a wave whose other lanes are longer) are computed with
 // sentinel symbols that never match; with miss < 0 and gap < 0 such a cell is strictly smaller than some real cell
 // (or 0), so it never wins the maximum, and the walker never visits it.
+#include <type_traits>
+
 #include "sw_internal.h"
 
 namespace swhip {
@@ -54,6 +56,27 @@ typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 // symbol i (0..7) of eight u16 held in four dwords
 __device__ __forceinline__ uint32_t sym8(const u4& w, int i) {
   const uint32_t d = i < 2 ? w.x : (i < 4 ? w.y : (i < 6 ? w.z : w.w));
+  return (i & 1) ? (d >> 16) : (d & 0xffffu);
+}
+
+// Rows per hand-over block: the strip to the right may start a block once the whole block has been published, so
+// the block is what a strip trails its left neighbour by (plus one block of prefetch and the memory latency);
+// 4 rows instead of 8 took the 63-strip pipelines of 1 kb pairs from 3.0 to 2.x ms (profiles/r03_lanes_*).
+#ifndef SW_LANES_RB
+#define SW_LANES_RB 4
+#endif
+constexpr int RB = SW_LANES_RB;
+// back-off of a wave that waits for its left neighbour, in units of 64 clocks: a polling wave takes issue slots from
+// the working waves of its SIMD (one poll is ~60 instructions), so it sleeps several hundred clocks between polls
+#ifndef SW_LANES_SLEEP
+#define SW_LANES_SLEEP 16
+#endif
+static_assert(RB == 4 || RB == 8, "a block is 4 or 8 rows: 8 or 16 bytes of query symbols");
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef std::conditional<RB == 8, u4, u2v>::type qv_t;
+__device__ __forceinline__ uint32_t symq(const u4& w, int i) { return sym8(w, i); }
+__device__ __forceinline__ uint32_t symq(const u2v& w, int i) {
+  const uint32_t d = i < 2 ? w.x : w.y;
   return (i & 1) ? (d >> 16) : (d & 0xffffu);
 }
 
@@ -110,7 +133,7 @@ __global__ void __launch_bounds__(64) sw_lanes_kernel(LanesWork W, int match, in
   K.scX = (int)(((uint32_t)miss << 16) | 3u);
   K.lsub = ((uint32_t)(-gap) << 16) - 1u;
   K.usub = ((uint32_t)(-gap) << 16) - 2u;
-  const uint32_t nblk = G.Qmax / 8;  // (Qmax is a multiple of 8)
+  const uint32_t nblk = G.Qmax / RB;  // (Qmax is a multiple of 8)
 #ifndef SW_LANES_TIMING_NO_WAIT
   const uint32_t tag_in = s, tag_out = s + 1;
 #else  // (timing experiment: every tag reads as published -- results are garbage)
@@ -142,20 +165,20 @@ __global__ void __launch_bounds__(64) sw_lanes_kernel(LanesWork W, int match, in
     return __hip_atomic_load(hb + (size_t)r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
   // boundary column and query symbols of the first block
-  uint32_t hbn[8];
-  u4 qn = {0, 0, 0, 0};
+  uint32_t hbn[RB];
+  qv_t qn = {};
 #pragma unroll
-  for (int i = 0; i < 8; i++) hbn[i] = s ? load_hb((uint32_t)i) : 0u;
-  if (0 < Q) qn = *(gptr<const u4>)(pool + P.qoff);
+  for (int i = 0; i < RB; i++) hbn[i] = s ? load_hb((uint32_t)i) : 0u;
+  if (0 < Q) qn = *(gptr<const qv_t>)(pool + P.qoff);
   for (uint32_t rb = 0; rb < nblk; rb++) {
     if (s) {
       // Every row of this block must come from the strip to my left; normally it does (fetched a block ago).  The
       // re-poll is a slow path of its own that ends with nothing of its own in flight, so that the fast path carries
-      // no wait for it: a wait after the merge would also wait for the previous block's 16 stores.
+      // no wait for it: a wait after the merge would also wait for the previous block's stores.
       auto stale = [&]() -> bool {
         uint32_t bad = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) bad |= hbn[i] ^ tag_in;
+        for (int i = 0; i < RB; i++) bad |= hbn[i] ^ tag_in;
         return __builtin_amdgcn_ballot_w64((bad & 0xffffu) != 0) != 0;
       };
       if (stale()) {
@@ -168,30 +191,30 @@ __global__ void __launch_bounds__(64) sw_lanes_kernel(LanesWork W, int match, in
               asm volatile("s_endpgm" ::: "memory");
             }
           }
-          __builtin_amdgcn_s_sleep(2);
+          __builtin_amdgcn_s_sleep(SW_LANES_SLEEP);
 #pragma unroll
-          for (int i = 0; i < 8; i++)
-            if ((hbn[i] ^ tag_in) & 0xffffu) hbn[i] = load_hb(rb * 8 + (uint32_t)i);
+          for (int i = 0; i < RB; i++)
+            if ((hbn[i] ^ tag_in) & 0xffffu) hbn[i] = load_hb(rb * RB + (uint32_t)i);
           __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loads above (and everything older) have landed
           if (!stale()) break;
         }
       }
     }
-    uint32_t hbc[8];
+    uint32_t hbc[RB];
 #pragma unroll
-    for (int i = 0; i < 8; i++) hbc[i] = hbn[i] & 0xffff0000u;
-    const u4 qc = qn;
+    for (int i = 0; i < RB; i++) hbc[i] = hbn[i] & 0xffff0000u;
+    const qv_t qc = qn;
     if (rb + 1 < nblk) {  // next block's inputs, in flight while this one is computed
       if (s) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) hbn[i] = load_hb((rb + 1) * 8 + (uint32_t)i);
+        for (int i = 0; i < RB; i++) hbn[i] = load_hb((rb + 1) * RB + (uint32_t)i);
       }
-      if ((rb + 1) * 8 < Q) qn = *(gptr<const u4>)(pool + P.qoff + (rb + 1) * 8);
+      if ((rb + 1) * RB < Q) qn = *(gptr<const qv_t>)(pool + P.qoff + (rb + 1) * RB);
     }
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const uint32_t r = rb * 8 + (uint32_t)i;
-      const uint32_t q = r < Q ? sym8(qc, i) : kSentQ;
+    for (int i = 0; i < RB; i++) {
+      const uint32_t r = rb * RB + (uint32_t)i;
+      const uint32_t q = r < Q ? symq(qc, i) : kSentQ;
       uint32_t acc = 0, hright;
       lane_row(q, t, H, colkey, hbc[i], hdiag, 0xffffu - r, K, acc, hright);
       hdiag = hbc[i];

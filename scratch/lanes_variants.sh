@@ -6,8 +6,8 @@ cd "$(dirname "$0")/.."
 V=gpurun_variants
 if [ "$1" = build ]; then
   mkdir -p $V
-  for v in NO_DIRS NO_WAIT "NO_DIRS -DSW_LANES_TIMING_NO_WAIT"; do
-    name=$(echo $v | tr -d ' ' | tr -c 'A-Z_\n' '_')
+  for v in NO_WAIT "X -DSW_LANES_SLEEP=4" "X -DSW_LANES_SLEEP=8" "X -DSW_LANES_SLEEP=32" "X -DSW_LANES_SLEEP=64" "X -DSW_LANES_RB=8"; do
+    name=$(echo $v | tr -d ' ' | tr -c 'A-Z0-9_\n' '_')
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -x hip dlsa_amd/csrc/sw_lanes.hip -DSW_LANES_TIMING_$v -o $V/sw_lanes_$name.o
     objs=$(ls dlsa_amd/lib/obj/*.o | grep -v sw_lanes.hip.o)
     hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o $V/libsw_$name.so $objs $V/sw_lanes_$name.o
