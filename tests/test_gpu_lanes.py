@@ -164,3 +164,56 @@ def test_big_batch_of_reads_takes_the_lane_path_by_itself(oracle, lanes_env):
     lanes_env("0")
     ref, _ = _run(qs[:4000], ts[:4000], sc, 0)
     assert [_tuple(x) for x in res[:4000]] == [_tuple(x) for x in ref]
+
+
+def test_execute_work_through_the_lane_kernel_equals_the_go_worker_on_the_oracle(oracle, lanes_env):
+    """sw_execute_work (fallback chain, sign flip, int() conversions) with every eligible pair on the lane kernel:
+    empty and non-ASCII sequences take the other paths inside the same call."""
+    import test_gpu_worker as tw
+    from dlsa_amd import worker
+    lanes_env("1")
+    rng = random.Random(71)
+    work = tw._package(rng, 5, 60)
+    w = worker.Worker()
+    w.execute_work(work, work.queries)
+    details = [d for r in w.sent for d in r.alignments]
+    assert len(details) == len(work.queries)
+    for comb, d in zip(work.queries, details):
+        e = tw._expected(oracle, work, comb)
+        a = d.alignment
+        assert (a.query_alignment, a.target_alignment) == (e["q"], e["t"]), (comb,)
+        assert a.score == e["score"] & 0xFFFF
+        assert (a.maxX, a.maxY) == (tw._go_int(e["max_x"]), tw._go_int(e["max_y"]))
+        assert d.entry == e["which"]
+
+
+def test_long_pairs_many_strips_identical_and_unrelated(oracle, lanes_env):
+    """3 kb pairs: 188 strips per group chained through the tagged boundary column; identical sequences give one
+    long diagonal (score 2 x length, the traceback crosses every strip), unrelated ones a gappy path."""
+    lanes_env("1")
+    rng = random.Random(73)
+    sc = (-1, 2, -1)
+    a = _rnd(rng, 3000)
+    qs = [a, a, _rnd(rng, 2900), a[:2500], _rnd(rng, 1500)]
+    ts = [a, _rnd(rng, 3000), a, a[300:], "".join(c if rng.random() > 0.08 else rng.choice("ACGT") for c in a[:1700])]
+    res, n_lane = _run(qs, ts, sc, 1)
+    assert n_lane == len(qs)
+    _check_all(oracle, qs, ts, sc, 1, res)
+
+
+def test_node_batch_over_logical_shards_with_the_lane_kernel(oracle, lanes_env):
+    """sw_node_align_batch cuts the pair list into one part per shard; every part may take the lane path on its
+    device's context (two logical shards on device 0 here)."""
+    import dlsa_amd
+    from dlsa_amd import bridge
+    lanes_env("1")
+    rng = random.Random(79)
+    sc = (-1, 2, -1)
+    qs = [_rnd(rng, rng.randint(40, 200)) for _ in range(300)]
+    ts = [_rnd(rng, rng.randint(40, 200)) for _ in range(300)]
+    node = bridge.Node(devices=[0, 0])
+    try:
+        res = bridge.align_batch(qs, ts, dlsa_amd.AlignmentScore(2, -1, -1), 0, node=node)
+    finally:
+        node.close()
+    _check_all(oracle, qs, ts, sc, 0, res)
