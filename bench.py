@@ -116,10 +116,10 @@ def _sum_stats(per_shard):
 
 
 def load_pmc_traffic(key):
-    """HBM bytes per score-kernel launch from the committed PMC passes (profiles/r02_pmc.json), if the workload is
+    """HBM bytes per score-kernel launch from the committed PMC passes (profiles/r03_pmc.json), if the workload is
     one that was profiled; counters cannot be read from inside this process."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc.json")) as f:
             return json.load(f).get(key)
     except (OSError, ValueError):
         return None
