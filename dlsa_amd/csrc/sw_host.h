@@ -117,9 +117,12 @@ struct Context {
   int device = 0;
   int cus = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;  // the lane path's second slice in flight (sw_lanes.cpp)
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   Workspace ws;
   Workspace ws2;  // second set for submissions in flight while the first is being read back (work packages)
+  DevBuf sympool;  // the lane path's copy of a batch's symbol block (SymPool)
+  hipEvent_t ev_pool = nullptr;  // ... uploaded (made on first use)
   // the allocation-free entry point (sw_db_scores_noalloc): windows of this device's copy of the static scratch
   // array (sw_lib.cpp) and a host arena, both bound once when the context is created
   Workspace na;
@@ -240,6 +243,10 @@ struct PairOut {
   uint32_t bx = 0, bj = 0;
   size_t ops_off = 0;  // traceback ops (last alignment column first) at arena[ops_off .. ops_off + nops)
   uint32_t nops = 0;
+  // != 0 (the lane kernel, ASCII pairs only): the arena holds the two ALIGNED STRINGS instead of ops, in reading
+  // order -- the query alignment at arena[ops_off, ops_off + nops), the target alignment nops bytes from the next
+  // multiple of 4 after it
+  uint32_t strings = 0;
   uint32_t end_x = 0, end_j = 0;  // where the walker stopped (window-local column; 0 = the boundary column)
   int32_t end_H = 0;
   uint64_t key = ~0ull;           // discovery-order key of the best cell (global column)
@@ -275,7 +282,8 @@ struct PinnedNoInitAlloc {
 using OpsArena = std::vector<uint8_t, PinnedNoInitAlloc<uint8_t>>;
 struct ArenaLease {
   OpsArena a;
-  ArenaLease();
+  // want: bytes the caller is going to need (the smallest pooled block that holds them; 0: the largest block)
+  explicit ArenaLease(size_t want = 0);
   ~ArenaLease();
   ArenaLease(const ArenaLease&) = delete;
   ArenaLease& operator=(const ArenaLease&) = delete;
@@ -291,6 +299,7 @@ int run_exact(Context& c, Workspace& ws, const PairSpec* specs, size_t n, Scorin
 // For the pairs it is eligible for, fills po[k] (global end cell, score, ops appended to `arena`) and sets
 // handled[k]; everything else is left to the whole-matrix path.  dec: the distinct decoded sequences of the batch;
 // pair_q / pair_t: per pair, indices into dec.  Takes the lock of `device`'s context (-1: the default device) itself.
+constexpr size_t kWindowsMinTarget = 2048;  // symbols of the shortest target the fast path takes
 int align_windows(const std::vector<Decoded>& dec, const std::vector<uint32_t>& pair_q, const std::vector<uint32_t>& pair_t,
                   Scoring sc, std::vector<PairOut>& po, OpsArena& arena, std::vector<uint8_t>& handled,
                   int device = -1);
@@ -302,8 +311,15 @@ int align_windows(const std::vector<Decoded>& dec, const std::vector<uint32_t>& 
 // the next slice is on the GPU (the arena does not move until the call returns: the ops of every slice have their
 // place in it from the start).
 using LanesReady = std::function<void(const uint32_t* ks, size_t m)>;
+// Optional: the symbols of every sequence of the batch as ONE page-locked block in which each sequence starts at a
+// multiple of 8 symbols (align_interned decodes into such a block).  The lane path then uploads the block once and
+// addresses it by offsets, instead of gathering the distinct sequences of every slice into a staging buffer.
+struct SymPool {
+  const uint16_t* base = nullptr;
+  size_t syms = 0;
+};
 int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* small_syms, Scoring sc, PairOut* po,
-                OpsArena& arena, uint8_t* handled, const LanesReady& ready = nullptr);
+                OpsArena& arena, uint8_t* handled, const LanesReady& ready = nullptr, const SymPool* syms = nullptr);
 // A batch of pairs on one device (sw_lib.cpp): the body of sw_align_batch.  out[i] = NULL for a pair the reference
 // would have failed on; a non-zero return means nothing was handed over.
 int align_many_on(int device, const char* const* queries, const char* const* targets, size_t n, AlignmentScores as,

@@ -139,7 +139,8 @@ struct LanePair {       // lane l of group g: lanes[g * 64 + l]
   uint32_t Q, T;        // rows; columns computed (Tlim of the path).  Q == 0: idle lane
   uint32_t pair;        // output slot
   uint32_t pad_;
-  uint64_t ops_off;     // traceback ops of this pair in LanesWork::ops (capacity Q + T)
+  uint64_t ops_off;     // this pair's region in LanesWork::ops: Q + T bytes for the query alignment, then Q + T for
+                        // the target alignment; the walker fills both from their ends (sw_lanes.hip)
 };
 struct LaneGroup {      // 64 pairs: one wave per 16-column strip
   uint32_t Qmax;        // rows a wave runs: max Q of the group's lanes, rounded up to 8
@@ -156,16 +157,22 @@ struct LaneRec {        // best cell of one lane within one strip
 };
 struct LaneOut {
   int32_t score;        // H of the best cell (0: no hit)
-  uint32_t bx, bj;      // best cell, 1-based (0: none)
-  uint32_t nops;        // traceback ops written by the walker
+  uint32_t bxbj;        // best cell, 1-based: bx | bj << 16 (0: none; Q + T < 65000 on this path)
+  uint32_t nops;        // alignment columns found by the walker
+  uint32_t off16;       // where the packer put the pair's two aligned strings in LanesWork::dense, in 16-byte units:
+                        // the query alignment (nops bytes), then at the next multiple of 4 the target alignment
 };
+// bytes a pair of `nops` alignment columns takes in LanesWork::dense
+__host__ __device__ inline uint32_t lanes_dense_bytes(uint32_t nops) { return (2u * ((nops + 3u) & ~3u) + 15u) & ~15u; }
 struct LanesWork {
   const LaneGroup* groups;
   const LanePair* lanes;
   const uint16_t* pool;  // symbols; padded so that 32-byte loads at any sequence start + multiple of 16 stay inside
   uint32_t* dirs;
   uint32_t* hb;
-  uint8_t* ops;
+  uint8_t* ops;          // staging of the walker (LanePair::ops_off); never leaves the device
+  uint8_t* dense;        // the aligned strings of all pairs, packed (LaneOut::off16): what the host copies back
+  uint32_t* dense_used;  // bytes of `dense` handed out so far (zeroed)
   LaneOut* outs;
   LaneRec* recs;
   const uint32_t* units;  // per ticket: strip << 20 | group, strip level by level (a strip's left neighbour first)

@@ -6,6 +6,7 @@
 // (sw_exact.hip) bit for bit: same score, same first maximal cell in the reference's discovery order, same
 // traceback (tests/test_gpu_lanes.py compares both with the oracle).
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <unordered_map>
 
@@ -32,25 +33,45 @@ struct Elig {
 }  // namespace
 
 int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* small_syms, Scoring sc, PairOut* po,
-                OpsArena& arena, uint8_t* handled, const LanesReady& ready) {
+                OpsArena& arena, uint8_t* handled, const LanesReady& ready, const SymPool* syms) {
   const int mode = lanes_mode();
   if (mode == 0 || n == 0) return SW_OK;
   // the kernel's domain: sentinel cells lose only if every step off a match costs something
   if (!(sc.match > 0 && sc.miss < 0 && sc.gap < 0)) return SW_OK;
   StageTimer tm(n);
+  // (on the host threads: a package of reads is 10^5 pairs)
+  std::vector<Elig> cand(n);
+  std::vector<uint8_t> is_el(n, 0);
+  // (for the choice between one upload of the caller's symbol block and per-slice staging, below)
+  std::atomic<uint64_t> syms_unshared{0};
+  std::atomic<bool> all_in_block{syms && syms->base && syms->syms};
+  parallel_ranges(n, n * 64, [&](size_t lo, size_t hi) {
+    uint64_t mine = 0;
+    bool inside = true;
+    for (size_t k = lo; k < hi; k++) {
+      if (handled[k] || !small_syms[k]) continue;
+      const PairSpec& s = specs[k];
+      if (s.path == SW_PATH_STRAIGHT || s.left || s.col0 || s.Tfull || s.Qfull || s.walk_x) continue;
+      if (s.Q == 0 || s.T == 0 || (uint64_t)s.Q + s.T > 65000u) continue;
+      const PathParams pp = resolve_path(s.path, s.Q, s.T);
+      if (pp.phaseQp || pp.straight || pp.Tlim == 0 || pp.T0 < pp.Tlim) continue;
+      // V = H << 16 | tag must stay a non-negative int32
+      if ((uint64_t)std::min(s.Q, pp.Tlim) * (uint64_t)sc.match > 32767u) continue;
+      cand[k] = Elig{(uint32_t)k, s.Q, pp.Tlim, pp.T0 > pp.Tlim};
+      is_el[k] = 1;
+      mine += (uint64_t)s.Q + s.T;
+      if (syms && inside)
+        inside = s.q >= syms->base && s.q + s.Q <= syms->base + syms->syms && s.t >= syms->base &&
+                 s.t + s.T <= syms->base + syms->syms && ((s.q - syms->base) & 7) == 0 && ((s.t - syms->base) & 7) == 0;
+    }
+    syms_unshared.fetch_add(mine);
+    if (!inside) all_in_block.store(false);
+  });
   std::vector<Elig> el;
   el.reserve(n);
-  for (size_t k = 0; k < n; k++) {
-    if (handled[k] || !small_syms[k]) continue;
-    const PairSpec& s = specs[k];
-    if (s.path == SW_PATH_STRAIGHT || s.left || s.col0 || s.Tfull || s.Qfull || s.walk_x) continue;
-    if (s.Q == 0 || s.T == 0 || (uint64_t)s.Q + s.T > 65000u) continue;
-    const PathParams pp = resolve_path(s.path, s.Q, s.T);
-    if (pp.phaseQp || pp.straight || pp.Tlim == 0 || pp.T0 < pp.Tlim) continue;
-    // V = H << 16 | tag must stay a non-negative int32
-    if ((uint64_t)std::min(s.Q, pp.Tlim) * (uint64_t)sc.match > 32767u) continue;
-    el.push_back(Elig{(uint32_t)k, s.Q, pp.Tlim, pp.T0 > pp.Tlim});
-  }
+  for (size_t k = 0; k < n; k++)
+    if (is_el[k]) el.push_back(cand[k]);
+  std::vector<Elig>().swap(cand);
   if (el.empty()) return SW_OK;
   // length-sorted (rows, then columns, descending): the lanes of a wave run max rows x max strips of their group
   const bool sorted = std::is_sorted(el.begin(), el.end(), [](const Elig& a, const Elig& b) {
@@ -98,20 +119,34 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
     for (hipEvent_t* e : {&w->ev_k0, &w->ev_k1, &w->ev_done})
       if (!*e && hipEventCreate(e) != hipSuccess) return fail(SW_E_HIP, "hipEventCreate");
 
+  // The symbols: when the caller decoded the batch into one page-locked block (SymPool) that is no bigger than what
+  // the slices would gather anyway, the block is uploaded ONCE, as it is, and a pair names its sequences by offset --
+  // no per-slice gathering of distinct sequences, no staging copy.  Otherwise every slice stages its own pool.
+  // (the block must not be more than staging without any sharing would copy; every eligible pair's sequences lie in
+  // it at multiples of 8 symbols by construction -- a spec from elsewhere turns the choice off)
+  const bool whole_pool = all_in_block.load() && syms->syms < 0x7fffff00u && syms->syms <= syms_unshared.load() &&
+                          syms->syms * 2 <= c.scratch_budget / 4;
+  if (whole_pool) {
+    int erc;
+    if ((erc = c.sympool.ensure(syms->syms * 2 + 256))) return erc;
+    if (!c.ev_pool && hipEventCreate(&c.ev_pool) != hipSuccess) return fail(SW_E_HIP, "hipEventCreate");
+  }
+
   // Slices of groups: each fits the scratch budget (direction words dominate: rows x strips x 256 bytes per group),
   // and a big batch is cut into a few slices anyway so that TWO are in flight -- while slice i is on the GPU, slice
   // i + 1 is staged and queued behind it on the second workspace, and the caller's `ready` (string assembly, on
   // another thread) works on slice i - 1.
   struct Slice {
-    size_t g0 = 0, g1 = 0, dir_words = 0, hb_words = 0, ops_base = 0, ops_bytes = 0, n_units = 0;
-    std::vector<LanePair> lanes;
+    size_t g0 = 0, g1 = 0, dir_words = 0, hb_words = 0, n_units = 0;
+    size_t dense_cap = 0;   // most bytes the packed strings of the slice can take ...
+    size_t dense_base = 0;  // ... and where they go in the arena (relative to arena_base)
     uint64_t cells = 0;
   };
   std::vector<Slice> slices;
   {
     // (two slices at least for a batch worth pipelining; beyond that a slice keeps >= 2048 waves so that it still
     // fills the GPU's 1024 SIMDs twice over)
-    const size_t want = el.size() >= 32768 ? std::min<size_t>(16, std::max<size_t>(2, el.size() / 131072)) : 1;
+    const size_t want = el.size() >= 32768 ? std::min<size_t>(16, std::max<size_t>(2, el.size() / 32768)) : 1;
     const size_t per = (n_groups + want - 1) / want;
     size_t g0 = 0;
     while (g0 < n_groups) {
@@ -121,6 +156,11 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
       while (g1 < n_groups && g1 - g0 < per && g1 - g0 < 0xfffffu && sl.n_units < 0x7ff00000u) {
         const size_t dw = (size_t)groups[g1].Qmax * groups[g1].nstrips * 64, hw = (size_t)groups[g1].Qmax * 64;
         if (g1 > g0 && (sl.dir_words + dw + sl.hb_words + hw) * 4 > c.scratch_budget / 2) break;
+        // (the packed strings of a slice are addressed by a 32-bit byte counter on the device)
+        size_t dense = 0;
+        for (size_t i = g1 * 64; i < std::min(el.size(), g1 * 64 + 64); i++) dense += lanes_dense_bytes(el[i].Q + el[i].T);
+        if (g1 > g0 && sl.dense_cap + dense > 0xc0000000u) break;
+        sl.dense_cap += dense;
         groups[g1].dirs_off = sl.dir_words;
         groups[g1].hb_off = sl.hb_words;
         groups[g1].rec_off = (uint32_t)sl.n_units;
@@ -134,28 +174,52 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
       g0 = g1;
     }
   }
-  // the traceback ops of ALL slices: one stretch of the arena, sized once, so that nothing moves while `ready` reads
-  // the finished slices
-  size_t total_ops = 0;
+  // the aligned strings of ALL slices: one stretch of the arena, sized once for the longest paths possible, so that
+  // nothing moves while `ready` reads the finished slices (only what a slice really used is copied)
+  size_t total_dense = 0;
   for (Slice& sl : slices) {
-    sl.ops_base = total_ops;
-    const size_t p0 = sl.g0 * 64, p1 = std::min(el.size(), sl.g1 * 64);
-    for (size_t i = p0; i < p1; i++) total_ops += ((size_t)el[i].Q + specs[el[i].k].T + 15) & ~(size_t)15;
+    sl.dense_base = total_dense;
+    total_dense += sl.dense_cap;
   }
   const size_t arena_base = arena.size();
-  arena.resize(arena_base + total_ops);  // (page-locked: the copies land in place)
+  arena.resize(arena_base + total_dense);  // (page-locked: the copies land in place)
   tm.lap("lanes: slices");
 
   struct InFlight {
-    size_t np = 0, err_at = 0;
+    size_t np = 0, ctl_at = 0;
+    const uint8_t* d_dense = nullptr;
   } fl[2];
+  // a slice has its stream: the copies of one overlap the kernels of the other
+  hipStream_t streams[2] = {c.stream, c.stream2};
   auto align64 = [](size_t v) { return (v + 63) & ~(size_t)63; };
+  double t_stage[5] = {0, 0, 0, 0, 0};  // (SW_HIP_TRACE) lanes table, buffers, unit table, symbol pool, HIP calls
+  auto now_ms = [&]() { return tm.on ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0; };
   // stages slice `si` and queues it (copies in, kernels, copies out) on workspace `ws`; does not wait
   auto begin = [&](size_t si, Workspace& ws, InFlight& f) -> int {
     Slice& sl = slices[si];
+    const hipStream_t stream = streams[si & 1];
     const size_t p0 = sl.g0 * 64, p1 = std::min(el.size(), sl.g1 * 64), np = p1 - p0, ng = sl.g1 - sl.g0;
     f.np = np;
-    // symbol pool of the slice: every distinct sequence once, 16-byte aligned
+    double t_a = now_ms();
+    auto lapse = [&](int k) {
+      const double t_b = now_ms();
+      t_stage[k] += t_b - t_a;
+      t_a = t_b;
+    };
+    // where a pair's walker stages its strings (sw_lanes.hip): a running sum, the one serial step of the table
+    std::vector<uint64_t> stage_off(np + 1);
+    {
+      uint64_t at = 0;
+      for (size_t i = p0; i < p1; i++) {
+        stage_off[i - p0] = at;
+        at += (2 * ((uint64_t)el[i].Q + el[i].T) + 15) & ~(uint64_t)15;
+        sl.cells += (uint64_t)specs[el[i].k].Q * specs[el[i].k].T;
+      }
+      stage_off[np] = at;
+    }
+    const size_t ops_bytes = stage_off[np];
+    // symbol pool of the slice (unless the whole batch's block is on the device): every distinct sequence once,
+    // 16-byte aligned
     std::unordered_map<const uint16_t*, uint32_t> seen;
     std::vector<uint32_t> by_id;
     struct SeqCopy {
@@ -163,44 +227,43 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
       uint32_t len, off;
     };
     std::vector<SeqCopy> copies;
+    std::vector<uint32_t> qoffs, toffs;
     size_t pool_syms = 0;
-    auto add_seq = [&](const uint16_t* p, uint32_t len, uint32_t id) -> uint32_t {
-      if (id != UINT32_MAX) {
-        if (id >= by_id.size()) by_id.resize((size_t)id + 1 + by_id.size() / 2, UINT32_MAX);
-        if (by_id[id] != UINT32_MAX && copies[by_id[id]].p == p && copies[by_id[id]].len == len) return copies[by_id[id]].off;
-      } else {
-        auto it = seen.find(p);
-        if (it != seen.end() && copies[it->second].len == len) return copies[it->second].off;
+    if (!whole_pool) {
+      auto add_seq = [&](const uint16_t* p, uint32_t len, uint32_t id) -> uint32_t {
+        if (id != UINT32_MAX) {
+          if (id >= by_id.size()) by_id.resize((size_t)id + 1 + by_id.size() / 2, UINT32_MAX);
+          if (by_id[id] != UINT32_MAX && copies[by_id[id]].p == p && copies[by_id[id]].len == len) return copies[by_id[id]].off;
+        } else {
+          auto it = seen.find(p);
+          if (it != seen.end() && copies[it->second].len == len) return copies[it->second].off;
+        }
+        const uint32_t off = (uint32_t)pool_syms;
+        copies.push_back(SeqCopy{p, len, off});
+        pool_syms += ((size_t)len + 7) & ~(size_t)7;
+        if (id != UINT32_MAX) by_id[id] = (uint32_t)copies.size() - 1;
+        else seen[p] = (uint32_t)copies.size() - 1;
+        return off;
+      };
+      qoffs.resize(np);
+      toffs.resize(np);
+      for (size_t i = p0; i < p1; i++) {
+        const PairSpec& s = specs[el[i].k];
+        qoffs[i - p0] = add_seq(s.q, s.Q, s.qid);
+        toffs[i - p0] = add_seq(s.t, s.T, s.tid);
+        if (pool_syms > 0x7fffff00u) return fail(SW_E_ARG, "too many symbols in one submission");
       }
-      const uint32_t off = (uint32_t)pool_syms;
-      copies.push_back(SeqCopy{p, len, off});
-      pool_syms += ((size_t)len + 7) & ~(size_t)7;
-      if (id != UINT32_MAX) by_id[id] = (uint32_t)copies.size() - 1;
-      else seen[p] = (uint32_t)copies.size() - 1;
-      return off;
-    };
-    sl.lanes.assign(ng * 64, LanePair{});
-    size_t ops_bytes = 0;
-    for (size_t i = p0; i < p1; i++) {
-      const PairSpec& s = specs[el[i].k];
-      LanePair& lp = sl.lanes[i - p0];
-      lp.qoff = add_seq(s.q, s.Q, s.qid);
-      lp.toff = add_seq(s.t, s.T, s.tid);
-      if (pool_syms > 0x7fffff00u) return fail(SW_E_ARG, "too many symbols in one submission");
-      lp.Q = el[i].Q;
-      lp.T = el[i].T;
-      lp.pair = (uint32_t)(i - p0);
-      lp.ops_off = ops_bytes;
-      ops_bytes += ((size_t)s.Q + s.T + 15) & ~(size_t)15;
-      sl.cells += (uint64_t)s.Q * s.T;
+      pool_syms += 64;  // (the kernel loads 32 bytes at a sequence's last 16-symbol boundary)
     }
-    sl.ops_bytes = ops_bytes;
-    pool_syms += 64;  // (the kernel loads 32 bytes at a sequence's last 16-symbol boundary)
-    const size_t in_groups = 0, in_lanes = align64(ng * sizeof(LaneGroup)), in_units = in_lanes + align64(sl.lanes.size() * sizeof(LanePair)),
+    lapse(0);
+    const size_t n_lanes = ng * 64;
+    const size_t in_groups = 0, in_lanes = align64(ng * sizeof(LaneGroup)), in_units = in_lanes + align64(n_lanes * sizeof(LanePair)),
                  in_pool = in_units + align64(sl.n_units * 4);
     const size_t in_bytes = in_pool + align64(pool_syms * 2);
-    constexpr size_t kCtl = 256;  // control words in front of the boundary columns: [0] ticket, [32] error word
-    const size_t out_ops = align64(np * sizeof(LaneOut)), out_bytes = out_ops + align64(ops_bytes);
+    // control words in front of the boundary columns: [0] ticket, [32] error word, [33] bytes of packed strings
+    constexpr size_t kCtl = 256;
+    const size_t out_ops = align64(np * sizeof(LaneOut)), out_dense = out_ops + align64(ops_bytes),
+                 out_bytes = out_dense + align64(sl.dense_cap);
     int erc;
     if ((erc = ws.xin.ensure(in_bytes))) return erc;
     if ((erc = ws.h_in.ensure(in_bytes))) return erc;
@@ -209,7 +272,9 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
     if ((erc = ws.xrecs.ensure(std::max<size_t>(sl.n_units * 64 * sizeof(LaneRec), 16)))) return erc;
     if ((erc = ws.xout.ensure(out_bytes))) return erc;
     if ((erc = ws.h_out.ensure(out_ops + 16))) return erc;
+    f.ctl_at = out_ops;
     uint8_t* const h_in = (uint8_t*)ws.h_in.p;
+    lapse(1);
     {  // tickets strip level by level: a strip's left neighbour always holds an earlier ticket
       uint32_t* units = (uint32_t*)(h_in + in_units);
       uint32_t max_strips = 0;
@@ -220,43 +285,61 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
           if (groups[g].nstrips > st) units[u++] = (st << 20) | (uint32_t)(g - sl.g0);
     }
     memcpy(h_in + in_groups, groups.data() + sl.g0, ng * sizeof(LaneGroup));
-    memcpy(h_in + in_lanes, sl.lanes.data(), sl.lanes.size() * sizeof(LanePair));
-    uint16_t* const hpool = (uint16_t*)(h_in + in_pool);
-    parallel_ranges(copies.size(), pool_syms * 2, [&](size_t lo, size_t hi) {
-      for (size_t k = lo; k < hi; k++) {
-        memcpy(hpool + copies[k].off, copies[k].p, (size_t)copies[k].len * 2);
-        const size_t pad = (((size_t)copies[k].len + 7) & ~(size_t)7) - copies[k].len;
-        if (pad) memset(hpool + copies[k].off + copies[k].len, 0xff, pad * 2);
+    lapse(2);
+    // the lanes' table, straight into the staging buffer
+    LanePair* const hl = (LanePair*)(h_in + in_lanes);
+    parallel_ranges(n_lanes, n_lanes * 64, [&](size_t lo, size_t hi) {
+      for (size_t l = lo; l < hi; l++) {
+        LanePair lp{};
+        if (l < np) {
+          const Elig& e = el[p0 + l];
+          const PairSpec& sp = specs[e.k];
+          lp.qoff = whole_pool ? (uint32_t)(sp.q - syms->base) : qoffs[l];
+          lp.toff = whole_pool ? (uint32_t)(sp.t - syms->base) : toffs[l];
+          lp.Q = e.Q;
+          lp.T = e.T;
+          lp.pair = (uint32_t)l;
+          lp.ops_off = stage_off[l];
+        }
+        hl[l] = lp;
       }
     });
-    memset(hpool + pool_syms - 64, 0xff, 128);
-    HIPCK(hipMemcpyAsync(ws.xin.p, h_in, in_bytes, hipMemcpyHostToDevice, c.stream));
+    lapse(0);
+    if (!whole_pool) {
+      uint16_t* const hpool = (uint16_t*)(h_in + in_pool);
+      parallel_ranges(copies.size(), pool_syms * 2, [&](size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; k++) memcpy(hpool + copies[k].off, copies[k].p, (size_t)copies[k].len * 2);
+      });  // (what lies between the sequences is never looked at: the kernel masks by the lengths)
+    }
+    lapse(3);
+    HIPCK(hipMemcpyAsync(ws.xin.p, h_in, in_bytes, hipMemcpyHostToDevice, stream));
     // (a word of a boundary column is "published" by the tag in its low half, so the columns start at zero)
-    HIPCK(hipMemsetAsync(ws.xzero.p, 0, kCtl + sl.hb_words * 4, c.stream));
-    HIPCK(hipEventRecord(ws.ev_k0, c.stream));
+    HIPCK(hipMemsetAsync(ws.xzero.p, 0, kCtl + sl.hb_words * 4, stream));
+    HIPCK(hipEventRecord(ws.ev_k0, stream));
     LanesWork w{};
     w.groups = (const LaneGroup*)((uint8_t*)ws.xin.p + in_groups);
     w.lanes = (const LanePair*)((uint8_t*)ws.xin.p + in_lanes);
-    w.pool = (const uint16_t*)((uint8_t*)ws.xin.p + in_pool);
+    w.pool = whole_pool ? (const uint16_t*)c.sympool.p : (const uint16_t*)((uint8_t*)ws.xin.p + in_pool);
     w.dirs = (uint32_t*)ws.dirs.p;
     w.hb = (uint32_t*)((uint8_t*)ws.xzero.p + kCtl);
     w.recs = (LaneRec*)ws.xrecs.p;
     w.units = (const uint32_t*)((uint8_t*)ws.xin.p + in_units);
     w.ticket = (uint32_t*)ws.xzero.p;
     w.err = (uint32_t*)ws.xzero.p + 32;
+    w.dense_used = (uint32_t*)ws.xzero.p + 33;
     w.wait_ticks = exact_wait_ticks();
     w.n_units = (uint32_t)sl.n_units;
     w.ops = (uint8_t*)ws.xout.p + out_ops;
+    w.dense = (uint8_t*)ws.xout.p + out_dense;
     w.outs = (LaneOut*)ws.xout.p;
     w.n_groups = (uint32_t)ng;
-    HIPCK(launch_lanes(w, sc, true, c.stream));
-    HIPCK(hipEventRecord(ws.ev_k1, c.stream));
-    HIPCK(hipMemcpyAsync(ws.h_out.p, ws.xout.p, np * sizeof(LaneOut), hipMemcpyDeviceToHost, c.stream));
-    HIPCK(hipMemcpyAsync((uint8_t*)ws.h_out.p + out_ops, w.err, 4, hipMemcpyDeviceToHost, c.stream));
-    f.err_at = out_ops;
-    if (ops_bytes)
-      HIPCK(hipMemcpyAsync(arena.data() + arena_base + sl.ops_base, (uint8_t*)ws.xout.p + out_ops, ops_bytes, hipMemcpyDeviceToHost, c.stream));
-    HIPCK(hipEventRecord(ws.ev_done, c.stream));
+    f.d_dense = w.dense;
+    HIPCK(launch_lanes(w, sc, true, stream));
+    HIPCK(hipEventRecord(ws.ev_k1, stream));
+    HIPCK(hipMemcpyAsync(ws.h_out.p, ws.xout.p, np * sizeof(LaneOut), hipMemcpyDeviceToHost, stream));
+    HIPCK(hipMemcpyAsync((uint8_t*)ws.h_out.p + out_ops, w.err, 8, hipMemcpyDeviceToHost, stream));
+    HIPCK(hipEventRecord(ws.ev_done, stream));
+    lapse(4);
     return SW_OK;
   };
   // waits for slice `si` and hands its pairs to the caller
@@ -264,9 +347,17 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
   auto end = [&](size_t si, Workspace& ws, InFlight& f) -> int {
     Slice& sl = slices[si];
     const size_t p0 = sl.g0 * 64, p1 = p0 + f.np;
+    const hipStream_t stream = streams[si & 1];
     HIPCK(hipEventSynchronize(ws.ev_done));
-    if (*(const uint32_t*)((const uint8_t*)ws.h_out.p + f.err_at) != 0)
-      return fail(SW_E_HIP, "lane kernel: strip pipeline wait timed out");
+    const uint32_t* ctl = (const uint32_t*)((const uint8_t*)ws.h_out.p + f.ctl_at);
+    if (ctl[0] != 0) return fail(SW_E_HIP, "lane kernel: strip pipeline wait timed out");
+    // the strings the slice really has (the other slice's kernels run meanwhile, on the other stream)
+    const size_t dense_used = ctl[1];
+    if (dense_used > sl.dense_cap) return fail(SW_E_HIP, "lane kernel: packed strings beyond their bound");
+    if (dense_used) {
+      HIPCK(hipMemcpyAsync(arena.data() + arena_base + sl.dense_base, f.d_dense, dense_used, hipMemcpyDeviceToHost, stream));
+      HIPCK(hipStreamSynchronize(stream));
+    }
     float ms = 0;
     HIPCK(hipEventElapsedTime(&ms, ws.ev_k0, ws.ev_k1));
     c.stats.exact_kernel_ms += ms;
@@ -281,11 +372,12 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
       PairOut& r = po[el[i].k];
       r = PairOut{};
       r.score = o.score;
-      r.bx = o.bx;
-      r.bj = o.bj;
+      r.bx = o.bxbj & 0xffffu;
+      r.bj = o.bxbj >> 16;
       r.nops = o.nops;
-      r.ops_off = arena_base + sl.ops_base + sl.lanes[i - p0].ops_off;
-      r.key = o.score > 0 ? (((uint64_t)(o.bx + o.bj) << 31) | o.bx) : ~0ull;
+      r.ops_off = arena_base + sl.dense_base + (size_t)o.off16 * 16;
+      r.strings = 1;
+      r.key = o.score > 0 ? (((uint64_t)(r.bx + r.bj) << 31) | r.bx) : ~0ull;
       handled[el[i].k] = 1;
       ks.push_back(el[i].k);
     }
@@ -293,20 +385,37 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
     c.stats.lanes_cells += sl.cells;
     c.stats.lanes_pairs += ks.size();
     for (size_t g = sl.g0; g < sl.g1; g++) c.stats.lanes_padded_cells += (uint64_t)groups[g].Qmax * groups[g].nstrips * 16 * 64;
-    std::vector<LanePair>().swap(sl.lanes);
     if (ready && !ks.empty()) ready(ks.data(), ks.size());
     return SW_OK;
   };
-  StreamDrain drain(c.stream);  // (an error return must not leave copies in flight that write the arena or read h_in)
-  int rc = begin(0, *wss[0], fl[0]);
+  // (an error return must not leave copies in flight that write the arena or read h_in)
+  StreamDrain drain(c.stream), drain2(c.stream2);
+  if (whole_pool) {  // (both streams wait for it; the slices staged meanwhile queue behind it)
+    HIPCK(hipMemcpyAsync(c.sympool.p, syms->base, syms->syms * 2, hipMemcpyHostToDevice, c.stream));
+    HIPCK(hipEventRecord(c.ev_pool, c.stream));
+    HIPCK(hipStreamWaitEvent(c.stream2, c.ev_pool, 0));
+  }
+  double t_begin = 0, t_end = 0;  // (SW_HIP_TRACE: host time staging slices / waiting for and handing over slices)
+  auto timed = [&](double& acc, auto&& fn) -> int {
+    if (!tm.on) return fn();
+    const auto a = std::chrono::steady_clock::now();
+    const int r = fn();
+    acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    return r;
+  };
+  int rc = timed(t_begin, [&] { return begin(0, *wss[0], fl[0]); });
   for (size_t si = 0; si < slices.size() && !rc; si++) {
     int rc_next = SW_OK;
-    if (si + 1 < slices.size()) rc_next = begin(si + 1, *wss[(si + 1) & 1], fl[(si + 1) & 1]);
-    rc = end(si, *wss[si & 1], fl[si & 1]);
+    if (si + 1 < slices.size()) rc_next = timed(t_begin, [&] { return begin(si + 1, *wss[(si + 1) & 1], fl[(si + 1) & 1]); });
+    rc = timed(t_end, [&] { return end(si, *wss[si & 1], fl[si & 1]); });
     if (!rc) rc = rc_next;
   }
+  if (tm.on)
+    fprintf(stderr, "[sw_hip]   lanes: %zu slices, staging %.3f ms (table %.3f, buffers %.3f, units %.3f, symbols %.3f, HIP calls %.3f), waits + hand-over %.3f ms\n",
+            slices.size(), t_begin, t_stage[0], t_stage[1], t_stage[2], t_stage[3], t_stage[4], t_end);
   if (rc) return rc;
   drain.dismiss();
+  drain2.dismiss();
   tm.lap("lanes: submissions");
   (void)padded_cells;
   return SW_OK;

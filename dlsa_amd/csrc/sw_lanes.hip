@@ -246,19 +246,27 @@ __global__ void __launch_bounds__(64) sw_lanes_kernel(LanesWork W, int match, in
 }
 
 // Traceback: one LANE per pair follows the direction bits from the best cell until H reaches 0
-// (rust/src/algorithm/mod.rs:663-664) or an edge (:650).  ops[] receives, last alignment column first:
-// 0 = (q[x-1], t[j-1]), 1 = (q[x-1], '-'), 2 = ('-', t[j-1]) -- the walker of sw_exact.hip's convention.
+// (rust/src/algorithm/mod.rs:663-664) or an edge (:650).  It writes the two ALIGNED STRINGS themselves, not move
+// codes: a pair's region holds `cap` bytes for the query alignment followed by `cap` for the target alignment, and
+// the walk -- which meets the last alignment column first -- fills both from their ends backwards, so that the
+// finished strings are the last nops bytes of each half, in reading order: column (q[x-1], t[j-1]) for a diagonal
+// move, (q[x-1], '-') for a move up, ('-', t[j-1]) for a move left (algorithm/mod.rs:677-706).  Symbols are ASCII
+// on this path (the host admits nothing else), so a symbol is its byte.  The staging regions are sized for the
+// longest possible path (Q + T columns) and stay on the device: the wave then reserves, with one atomic, room for
+// the strings its 64 pairs really have in LanesWork::dense, and sw_lanes_pack_kernel moves them there -- the host
+// copies back what was used (a tenth of the staging for unrelated reads) and memcpy's two strings per pair.
 // The walk is a chain of dependent loads, tens of thousands of chains in flight.
 __global__ void __launch_bounds__(64) sw_lanes_walk_kernel(LanesWork W, int match, int miss, int gap) {
   const uint32_t lane = threadIdx.x;
   const uint32_t g = blockIdx.x;
   if (g >= W.n_groups) return;
   const LaneGroup G = W.groups[g];
-  const LanePair P = W.lanes[(size_t)g * 64 + lane];
-  if (!P.Q) return;
+  const LanePair P = W.lanes[(size_t)g * 64 + lane];  // (an idle lane, Q == 0, stays for the wave-wide reservation)
   const gptr<const uint16_t> pool = (gptr<const uint16_t>)W.pool;
   const gptr<const uint32_t> dirs = (gptr<const uint32_t>)W.dirs + G.dirs_off + lane;
-  const gptr<uint8_t> ops = (gptr<uint8_t>)W.ops + P.ops_off;
+  const uint32_t cap = P.Q + P.T;
+  const gptr<uint8_t> qa_end = (gptr<uint8_t>)W.ops + P.ops_off + cap;       // one past the query alignment's half
+  const gptr<uint8_t> ta_end = qa_end + cap;                                 // ... the target alignment's
   // the pair's best cell: largest H, then the reference's discovery order (smallest x + j, then smallest x)
   uint32_t bestH = 0, bestkey = 0xffffffffu;
   for (uint32_t s = 0; s < G.nstrips; s++) {
@@ -270,13 +278,13 @@ __global__ void __launch_bounds__(64) sw_lanes_walk_kernel(LanesWork W, int matc
 #ifdef SW_LANES_TIMING_NO_WAIT  // (timing experiment: the fill computed garbage, nothing may be walked)
   bestH = 0;
 #endif
+  if (!P.Q) bestH = 0;
   LaneOut o;
   o.score = (int32_t)bestH;
-  o.bx = bestH ? (bestkey & 0xffffu) : 0;
-  o.bj = bestH ? ((bestkey >> 16) - (bestkey & 0xffffu)) : 0;
+  const uint32_t bx = bestH ? (bestkey & 0xffffu) : 0, bj = bestH ? ((bestkey >> 16) - (bestkey & 0xffffu)) : 0;
+  o.bxbj = bx | (bj << 16);
   int H = o.score;
-  uint32_t x = o.bx, j = o.bj, n = 0;
-  const uint32_t cap = P.Q + P.T;
+  uint32_t x = bx, j = bj, n = 0;
   bool broken = false;
   // A BLOCK of the path per round of loads: the direction words and query symbols of 4 rows up from the current
   // cell (same strip) and 5 target symbols to its left are fetched together -- 13 independent loads, one memory
@@ -297,34 +305,75 @@ __global__ void __launch_bounds__(64) sw_lanes_walk_kernel(LanesWork W, int matc
     while (i < 4 && k < 5 && ((c0 - k) >> 4) == s) {
       const uint32_t wv = i == 0 ? w[0] : (i == 1 ? w[1] : (i == 2 ? w[2] : w[3]));
       const uint32_t code = (wv >> (((c0 - k) & 15u) * 2)) & 3u;
-      uint32_t op;
+      const uint32_t qv = i == 0 ? qs[0] : (i == 1 ? qs[1] : (i == 2 ? qs[2] : qs[3]));
+      const uint32_t tv = k == 0 ? ts[0] : (k == 1 ? ts[1] : (k == 2 ? ts[2] : (k == 3 ? ts[3] : ts[4])));
+      uint32_t qc, tc;  // this alignment column
       if (code == 3u) {
-        const uint32_t qv = i == 0 ? qs[0] : (i == 1 ? qs[1] : (i == 2 ? qs[2] : qs[3]));
-        const uint32_t tv = k == 0 ? ts[0] : (k == 1 ? ts[1] : (k == 2 ? ts[2] : (k == 3 ? ts[3] : ts[4])));
         H -= (qv == tv) ? match : miss;
         i++;
         k++;
-        op = 0;
+        qc = qv;
+        tc = tv;
       } else if (code == 2u) {
         H -= gap;
         i++;
-        op = 1;
+        qc = qv;
+        tc = '-';
       } else if (code == 1u) {
         H -= gap;
         k++;
-        op = 2;
+        qc = '-';
+        tc = tv;
       } else {
         broken = true;  // (code 0 with H > 0 cannot happen: every cell on the path had a winning candidate)
         break;
       }
-      ops[n++] = (uint8_t)op;
+      n++;
+      qa_end[-(ptrdiff_t)n] = (uint8_t)qc;
+      ta_end[-(ptrdiff_t)n] = (uint8_t)tc;
       if (H <= 0 || n >= cap || i > r0 || k > c0) break;  // done, or off the top / left edge
     }
     x = r0 + 1 - i;
     j = c0 + 1 - k;
   }
   o.nops = n;
-  W.outs[P.pair] = o;
+  // room in the packed output: an inclusive scan of the lanes' needs, one atomic per wave
+  const uint32_t need = P.Q ? lanes_dense_bytes(n) : 0;
+  uint32_t incl = need;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+    if ((int)lane >= d) incl += up;
+  }
+  uint32_t base = 0;
+  if (lane == 63) base = atomicAdd(W.dense_used, incl);
+  base = (uint32_t)__shfl((int)base, 63, 64);
+  o.off16 = (base + incl - need) >> 4;
+  if (P.Q) W.outs[P.pair] = o;
+}
+
+// Moves the aligned strings from the walker's staging into their packed place: one wave per pair, four bytes per
+// lane and step (the target alignment starts at a multiple of 4, so that every store is an aligned dword).
+__global__ void __launch_bounds__(256) sw_lanes_pack_kernel(LanesWork W) {
+  const uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (slot >= W.n_groups * 64) return;
+  const LanePair P = W.lanes[slot];
+  if (!P.Q) return;
+  const LaneOut o = W.outs[P.pair];
+  const uint32_t n = o.nops, cap = P.Q + P.T, n4 = (n + 3u) & ~3u;
+  const gptr<const uint8_t> src_q = (gptr<const uint8_t>)W.ops + P.ops_off + cap - n;
+  const gptr<const uint8_t> src_t = src_q + cap;
+  const gptr<uint32_t> dst = (gptr<uint32_t>)(W.dense + (size_t)o.off16 * 16);
+  for (uint32_t b = lane * 4; b < 2 * n4; b += 256) {
+    const bool second = b >= n4;
+    const gptr<const uint8_t> src = second ? src_t : src_q;
+    const uint32_t at = second ? b - n4 : b;
+    uint32_t v = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++)
+      if (at + k < n) v |= (uint32_t)src[at + k] << (8 * k);
+    dst[b >> 2] = v;
+  }
 }
 
 hipError_t launch_lanes(const LanesWork& w, Scoring sc, bool want_trace, hipStream_t stream) {
@@ -334,6 +383,9 @@ hipError_t launch_lanes(const LanesWork& w, Scoring sc, bool want_trace, hipStre
   if (e != hipSuccess) return e;
   (void)want_trace;  // (the walker also combines the strips' best cells: it always runs)
   hipLaunchKernelGGL(sw_lanes_walk_kernel, dim3(w.n_groups), dim3(64), 0, stream, w, sc.match, sc.miss, sc.gap);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(sw_lanes_pack_kernel, dim3(w.n_groups * 16), dim3(256), 0, stream, w);
   return hipGetLastError();
 }
 

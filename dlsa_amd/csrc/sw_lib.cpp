@@ -123,12 +123,14 @@ int ctx_create(int device, Context** out) {
       for (hipEvent_t e : {c->ev0, c->ev1, c->ev2, c->ev3})
         if (e) (void)hipEventDestroy(e);
       if (c->stream) (void)hipStreamDestroy(c->stream);
+      if (c->stream2) (void)hipStreamDestroy(c->stream2);
       if (c->na_host.base) (void)hipHostFree(c->na_host.base);
     }
   } undo{c.get()};
   c->device = device;
   c->cus = prop.multiProcessorCount;
   HIPCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   HIPCK(hipEventCreate(&c->ev0));
   HIPCK(hipEventCreate(&c->ev1));
   HIPCK(hipEventCreate(&c->ev2));
@@ -734,13 +736,17 @@ void swhip::ExactHost::trim() {
   std::vector<uint32_t>().swap(unit_order);
   std::vector<uint64_t>().swap(id_copy);
 }
-swhip::ArenaLease::ArenaLease() {
+swhip::ArenaLease::ArenaLease(size_t want) {
   std::lock_guard<std::mutex> lk(g_arena_mu);
   std::vector<OpsArena>& pool = arena_pool();
-  if (!pool.empty()) {  // the largest one: a worker's packages are of a kind
+  if (!pool.empty()) {  // the smallest one that is large enough, else the largest: a worker's packages are of a kind
     size_t best = 0;
-    for (size_t i = 1; i < pool.size(); i++)
-      if (pool[i].capacity() > pool[best].capacity()) best = i;
+    auto fits = [&](size_t i) { return want != 0 && pool[i].capacity() >= want; };
+    for (size_t i = 1; i < pool.size(); i++) {
+      const bool better = fits(best) ? (fits(i) && pool[i].capacity() < pool[best].capacity())
+                                     : (fits(i) || pool[i].capacity() > pool[best].capacity());
+      if (better) best = i;
+    }
     a.swap(pool[best]);
     pool.erase(pool.begin() + (std::ptrdiff_t)best);
   }
@@ -1112,23 +1118,41 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
       used[ti[i]] = 1;
     }
   }
+  tm.lap("  decode: used");
   std::vector<Decoded> dec(n_distinct);
   std::vector<uint8_t> ok(n_distinct, 0);
   std::vector<size_t> lens(n_distinct, 0);
   size_t total_bytes = 0;
   std::vector<size_t> sym_at(n_distinct, 0);
+  tm.lap("  decode: tables");
   parallel_ranges(n_distinct, n_distinct * 256, [&](size_t lo, size_t hi) {  // (a package of reads: 10^5 strlen calls)
     for (size_t d = lo; d < hi; d++)
       if (used[d] && distinct_p[d]) lens[d] = strlen(distinct_p[d]);
   });
+  size_t longest = 0;
   for (size_t d = 0; d < n_distinct; d++)
     if (used[d] && distinct_p[d]) {
       sym_at[d] = total_bytes;
-      total_bytes += lens[d];
+      total_bytes += (lens[d] + 7) & ~(size_t)7;  // (every sequence at a multiple of 8 symbols: SymPool)
+      longest = std::max(longest, lens[d]);
     }
-  // one pool for the symbols of all sequences (a sequence has at most as many symbols as bytes)
-  std::vector<uint16_t, NoInitAlloc<uint16_t>> sym_pool(total_bytes + 1);
-  for (size_t d = 0; d < n_distinct; d++) dec[d].sym.bind(sym_pool.data() + sym_at[d]);
+  tm.lap("  decode: strlen");
+  // One pool for the symbols of all sequences (a sequence has at most as many symbols as bytes).  A batch big enough
+  // for the lane kernel decodes into page-locked memory, which that path uploads as it is.
+  std::vector<uint16_t, NoInitAlloc<uint16_t>> sym_plain;
+  std::unique_ptr<ArenaLease> sym_lease;
+  uint16_t* sym_base = nullptr;
+  if (n >= 1024 && path != SW_PATH_STRAIGHT) {
+    sym_lease.reset(new ArenaLease((total_bytes + 8) * 2));
+    sym_lease->a.resize((total_bytes + 8) * 2);
+    sym_base = (uint16_t*)sym_lease->a.data();
+  } else {
+    sym_plain.resize(total_bytes + 8);
+    sym_base = sym_plain.data();
+  }
+  const SymPool sym_pool_desc{sym_lease ? sym_base : nullptr, total_bytes};
+  for (size_t d = 0; d < n_distinct; d++) dec[d].sym.bind(sym_base + sym_at[d]);
+  tm.lap("  decode: pool");
   parallel_ranges(n_distinct, total_bytes, [&](size_t lo, size_t hi) {
     for (size_t d = lo; d < hi; d++)  // bindings.rs:125 unwrap: invalid UTF-8 -> NULL
       ok[d] = used[d] && distinct_p[d] && decode(distinct_p[d], lens[d], dec[d]) && dec[d].sym.size() < 0x7fffff00u;
@@ -1137,7 +1161,7 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
   // (filled in place on the host threads; pairs the reference would fail on are squeezed out afterwards -- rare)
   std::vector<PairSpec> specs(n);
   std::vector<size_t> idx(n);
-  std::vector<uint8_t> valid(n);
+  std::vector<uint8_t> valid(n);  // 0: the pair fails as the reference's would; 1: valid; 3: valid and both ASCII
   parallel_ranges(n, n * 64, [&](size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; i++) {
       idx[i] = i;
@@ -1146,18 +1170,19 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
       const Decoded &q = dec[qi[i]], &t = dec[ti[i]];
       if (ring_div_by_zero(path, (uint32_t)q.sym.size(), (uint32_t)t.sym.size(), sc)) continue;
       specs[i] = PairSpec{q.sym.data(), (uint32_t)q.sym.size(), t.sym.data(), (uint32_t)t.sym.size(), path, qi[i], ti[i]};
-      valid[i] = 1;
+      valid[i] = (q.ascii && t.ascii) ? 3 : 1;
     }
   });
   {
     size_t w = 0;
     for (size_t i = 0; i < n; i++)
       if (valid[i]) {
-        if (w != i) specs[w] = specs[i], idx[w] = i;
+        if (w != i) specs[w] = specs[i], idx[w] = i, valid[w] = valid[i];
         w++;
       }
     specs.resize(w);
     idx.resize(w);
+    valid.resize(w);
   }
   std::vector<PairOut> po(specs.size());
   ArenaLease lease;
@@ -1166,12 +1191,15 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
   // The work-package fast path (sw_package.cpp) takes the pairs it is eligible for: long ACGT targets on the ring
   // path, filled by the packed score kernel and traced inside windows.  Same results, by construction and by test.
   std::vector<uint8_t> handled(specs.size(), 0);
-  if (path == SW_PATH_LOW_MEMORY && !specs.empty()) {
+  // (its shortest eligible target has kWindowsMinTarget symbols: a package of reads does not even build the tables)
+  if (path == SW_PATH_LOW_MEMORY && !specs.empty() && longest >= kWindowsMinTarget) {
     std::vector<uint32_t> pq(specs.size()), pt(specs.size());
     for (size_t k = 0; k < specs.size(); k++) pq[k] = qi[idx[k]], pt[k] = ti[idx[k]];
     const int rc = align_windows(dec, pq, pt, sc, po, arena, handled, device);
     if (rc) return rc;
     tm.lap("windows");
+  } else {
+    g_package_stats = PackageStats{};
   }
   // Results of pairs [k_lo, k_hi) as ONE slab: [Slab | ResultBox x pairs | per pair: StrHdr + query alignment + NUL,
   // StrHdr + target alignment + NUL].  ASCII pairs (the normal case) know their string lengths up front (= the
@@ -1210,19 +1238,24 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
           StrHdr* ht = (StrHdr*)((char*)slab + str_off[kk] + each);
           hq->magic = ht->magic = kStrMagicSlab;
           char *qa = (char*)(hq + 1), *ta = (char*)(ht + 1);
-          uint32_t nx = 0, nj = 0;
-          for (uint32_t c = 0; c < o.nops; c++) {
-            nx += ops[c] != 2;
-            nj += ops[c] != 1;
+          if (o.strings) {  // the lane kernel wrote the strings themselves (sw_lanes.hip)
+            memcpy(qa, ops, o.nops);
+            memcpy(ta, ops + (((size_t)o.nops + 3) & ~(size_t)3), o.nops);
+          } else {
+            uint32_t nx = 0, nj = 0;
+            for (uint32_t c = 0; c < o.nops; c++) {
+              nx += ops[c] != 2;
+              nj += ops[c] != 1;
+            }
+            uint32_t cx = o.bx - nx, cj = o.bj - nj;  // 0-based index of the first aligned symbol
+            size_t w = 0;
+            for (uint32_t c = o.nops; c-- > 0; w++) {
+              const uint8_t op = ops[c];
+              qa[w] = op == 2 ? '-' : q.src[cx++];
+              ta[w] = op == 1 ? '-' : t.src[cj++];
+            }
           }
-          uint32_t cx = o.bx - nx, cj = o.bj - nj;  // 0-based index of the first aligned symbol
-          size_t w = 0;
-          for (uint32_t c = o.nops; c-- > 0; w++) {
-            const uint8_t op = ops[c];
-            qa[w] = op == 2 ? '-' : q.src[cx++];
-            ta[w] = op == 1 ? '-' : t.src[cj++];
-          }
-          qa[w] = ta[w] = 0;
+          qa[o.nops] = ta[o.nops] = 0;
           b->slab = slab;
           box_fill(b, qa, ta, path, o);
           mine += 3;
@@ -1251,8 +1284,8 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
   // next slice runs (one slab per slice).
   std::vector<uint8_t> emitted;
   if (path != SW_PATH_STRAIGHT && !specs.empty()) {
-    std::vector<uint8_t> small(specs.size());
-    for (size_t k = 0; k < specs.size(); k++) small[k] = dec[qi[idx[k]]].ascii && dec[ti[idx[k]]].ascii;
+    std::vector<uint8_t>& small = valid;  // (per pair: bit 1 = both sequences ASCII)
+    for (uint8_t& v : small) v >>= 1;
     struct {
       std::mutex mu;
       std::condition_variable cv;
@@ -1302,7 +1335,8 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
       lq.cv.notify_one();
     };
     const int rc = guarded<int>(SW_E_NOMEM, [&] {
-      return align_lanes(device, specs.data(), specs.size(), small.data(), sc, po.data(), arena, handled.data(), ready);
+      return align_lanes(device, specs.data(), specs.size(), small.data(), sc, po.data(), arena, handled.data(), ready,
+                         sym_pool_desc.base ? &sym_pool_desc : nullptr);
     });
     const std::string rc_err = rc ? last_error_string() : std::string();
     if (threaded) {
@@ -1324,10 +1358,11 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
   // (here) while the next is on the GPU (a second host thread drives it).  One slab per sub-batch.
   size_t scratch_est = 0;  // generous bound of the device scratch the pairs need together (direction bits dominate)
   uint64_t cells_est = 0;
-  for (const PairSpec& sp : specs) {
-    scratch_est += (size_t)sp.Q * sp.T / 3 + 16 * ((size_t)sp.Q + sp.T) + 4096;
-    cells_est += (uint64_t)sp.Q * sp.T;
-  }
+  if (n_handled == 0)
+    for (const PairSpec& sp : specs) {
+      scratch_est += (size_t)sp.Q * sp.T / 3 + 16 * ((size_t)sp.Q + sp.T) + 4096;
+      cells_est += (uint64_t)sp.Q * sp.T;
+    }
   // (many pairs, or a few thousand with milliseconds of GPU work: below that one submission is quicker)
   static const size_t pipe_min_pairs = [] {
     const char* e = getenv("SW_HIP_PIPE_MIN_PAIRS");

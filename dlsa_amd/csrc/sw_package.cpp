@@ -99,7 +99,7 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
   // ---- eligibility, grouped by query
   auto shape_ok = [&](size_t k) {
     const uint64_t Q = dec[pair_q[k]].sym.size(), T = dec[pair_t[k]].sym.size();
-    return !(Q < 32 || T < 2048 || T < 2 * Q || T < roundup64((uint32_t)Q) || Q * (uint64_t)sc.match >= 32767 || T >= 0x7fff0000ull);
+    return !(Q < 32 || T < kWindowsMinTarget || T < 2 * Q || T < roundup64((uint32_t)Q) || Q * (uint64_t)sc.match >= 32767 || T >= 0x7fff0000ull);
   };
   // which sequences are pure ACGT: those of the pairs that qualify by shape, scanned once each on the host threads
   std::vector<int8_t> acgt(dec.size(), -1);

@@ -59,17 +59,27 @@ static int execute_work(const sw_node* node, const sw_work_package* work, sw_ali
     return SW_E_ARG;
   }
   const uint64_t n = work->n_pairs;
-  for (uint64_t i = 0; i < n; i++) {
-    // worker_impl.go:116-122: both sequences must be in the package (the reference aborts the process)
-    if (work->pairs[i].query >= work->n_sequences || work->pairs[i].target >= work->n_sequences ||
-        !work->sequences[work->pairs[i].query] || !work->sequences[work->pairs[i].target]) {
-      set_last_error("sw_execute_work: target and query not found in work package (pair " + std::to_string(i) + ")");
-      return SW_E_ARG;
+  // (on the host threads: a caller's fresh array of 10^5 records is megabytes of first-touch pages)
+  std::atomic<uint64_t> first_bad{UINT64_MAX};
+  swhip::parallel_ranges(n, n * 96, [&](size_t lo, size_t hi) {
+    for (uint64_t i = lo; i < hi; i++) {
+      // worker_impl.go:116-122: both sequences must be in the package (the reference aborts the process)
+      if (work->pairs[i].query >= work->n_sequences || work->pairs[i].target >= work->n_sequences ||
+          !work->sequences[work->pairs[i].query] || !work->sequences[work->pairs[i].target]) {
+        uint64_t seen = first_bad.load();
+        while (i < seen && !first_bad.compare_exchange_weak(seen, i)) {
+        }
+        return;
+      }
+      out[i] = sw_alignment_detail{};
+      out[i].query = work->pairs[i].query;
+      out[i].target = work->pairs[i].target;
+      out[i].entry = -1;
     }
-    out[i] = sw_alignment_detail{};
-    out[i].query = work->pairs[i].query;
-    out[i].target = work->pairs[i].target;
-    out[i].entry = -1;
+  });
+  if (first_bad.load() != UINT64_MAX) {
+    set_last_error("sw_execute_work: target and query not found in work package (pair " + std::to_string(first_bad.load()) + ")");
+    return SW_E_ARG;
   }
   // worker_impl.go:126-127: {MatchScore, -MismatchPenalty, -GapPenalty}; worker_rust_bridge.go:108-112: C.ushort(...)
   out_initialised = true;

@@ -217,3 +217,25 @@ def test_node_batch_over_logical_shards_with_the_lane_kernel(oracle, lanes_env):
     finally:
         node.close()
     _check_all(oracle, qs, ts, sc, 0, res)
+
+
+def test_symbol_block_of_the_batch_or_per_slice_staging(oracle, lanes_env):
+    """A batch of >= 1024 pairs is decoded into one page-locked block that the lane path uploads as it is; when the
+    block holds much more than the eligible pairs need (long sequences of pairs that go elsewhere), every slice
+    stages its own symbols instead.  Same results either way."""
+    lanes_env("1")
+    rng = random.Random(83)
+    sc = (-1, 2, -1)
+    reads = [_rnd(rng, rng.randint(30, 90)) for _ in range(200)]
+    qs = [reads[rng.randrange(200)] for _ in range(1300)]
+    ts = [reads[rng.randrange(200)] for _ in range(1300)]
+    a, n_a = _run(qs, ts, sc, 0)                      # the block: 200 reads, far less than 1300 pairs' worth
+    assert n_a > 1200, n_a                            # (a few ring-path pairs with T < Qp are not eligible)
+    long_t = [_rnd(rng, 50000, "ACGTé") for _ in range(6)]   # not ASCII: these pairs take the whole-matrix path
+    qs2 = qs + [_rnd(rng, 24) for _ in range(6)]
+    ts2 = ts + long_t
+    b, n_b = _run(qs2, ts2, sc, 0)                    # the block: 300 000 symbols for pairs that need 160 000
+    assert n_b == n_a
+    assert [_tuple(x) for x in a] == [_tuple(x) for x in b[:1300]]
+    for i in list(range(0, 1300, 41)) + [1300, 1303]:
+        assert _tuple(b[i]) == _expect(oracle, 0, qs2[i], ts2[i], sc), i
