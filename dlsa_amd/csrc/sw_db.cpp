@@ -44,6 +44,10 @@ struct sw_db {
                                                           // in flight keeps its own reference: PersistPass)
   std::vector<uint32_t> generic;  // targets scored by the exact kernel only
   uint32_t max_len = 0;
+  // a TEMPORARY database (the work-package fast path builds one per target set and drops it a few milliseconds
+  // later): its device arrays are the context's (Context::tdb), not allocations of its own -- hipMalloc and above all
+  // hipFree, which waits for every stream of the device, would serialise the sets that run side by side
+  bool borrowed = false;
   // counters of THIS database's last search (phase A resets, phase B adds): several logical shards may share one
   // device context, whose own counters then belong to whichever shard ran last
   sw_kernel_stats last_stats{};
@@ -63,6 +67,11 @@ inline int nt_code(unsigned char ch) {
 
 void db_release(sw_db* db) {
   if (!db) return;
+  if (db->borrowed) {  // (caller holds the context's lock)
+    if (db->ctx) db->ctx->tdb.busy = false;
+    delete db;
+    return;
+  }
   if (db->d_words) (void)hipFree(db->d_words);
   if (db->d_lens) (void)hipFree(db->d_lens);
   if (db->d_slot_target) (void)hipFree(db->d_slot_target);
@@ -92,6 +101,33 @@ bool db_upload(sw_db* db, const std::vector<uint32_t>& words, const std::vector<
                const std::vector<uint32_t>& elem_group) {
   const size_t ngroups = db->groups.size();
   if (!ngroups) return true;
+  if (db->borrowed) {
+    Context& c = *db->ctx;
+    struct Part {
+      DevBuf* buf;
+      const void* src;
+      size_t bytes;
+      void** dst;
+    } parts[5] = {{&c.tdb.words, words.data(), words.size() * 4, (void**)&db->d_words},
+                  {&c.tdb.lens, lens.data(), lens.size() * 4, (void**)&db->d_lens},
+                  {&c.tdb.slot_target, db->slot_target.data(), lens.size() * 4, (void**)&db->d_slot_target},
+                  {&c.tdb.groups, db->groups.data(), ngroups * sizeof(ScoreGroup), (void**)&db->d_groups},
+                  {&c.tdb.elem_group, elem_group.data(), elem_group.size() * 4, (void**)&db->d_elem_group}};
+    for (Part& p : parts) {
+      if (p.buf->ensure(std::max<size_t>(p.bytes, 16))) return false;
+      *p.dst = p.buf->p;
+      if (hipMemcpyAsync(p.buf->p, p.src, p.bytes, hipMemcpyHostToDevice, c.stream) != hipSuccess) {
+        (void)hipStreamSynchronize(c.stream);
+        fail(SW_E_HIP, "hipMemcpy failed for the database");
+        return false;
+      }
+    }
+    if (hipStreamSynchronize(c.stream) != hipSuccess) {  // (the sources are the caller's temporaries)
+      fail(SW_E_HIP, "hipMemcpy failed for the database");
+      return false;
+    }
+    return true;
+  }
   if (hipMalloc(&db->d_words, words.size() * 4) != hipSuccess || hipMalloc(&db->d_lens, lens.size() * 4) != hipSuccess ||
       hipMalloc(&db->d_slot_target, lens.size() * 4) != hipSuccess ||
       hipMalloc(&db->d_groups, ngroups * sizeof(ScoreGroup)) != hipSuccess ||
@@ -124,10 +160,14 @@ inline uint32_t pack16(const unsigned char* p) { return pack8(p) | (pack8(p + 8)
 
 // Caller holds the context's lock (its device is current).
 // known_acgt: the caller has checked that every sequence consists of A, C, G, T only (the work-package fast path).
-sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off, bool known_acgt = false) {
+sw_db* db_build(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off, bool known_acgt = false, bool temporary = false) {
   std::unique_ptr<sw_db, DbDeleter> holder(new sw_db);  // an exception below must not leak the device arrays
   sw_db* db = holder.get();
   db->ctx = ctx;
+  if (temporary && !ctx->tdb.busy) {  // (one temporary database per context at a time; a second one allocates)
+    ctx->tdb.busy = true;
+    db->borrowed = true;
+  }
   db->n = off.size() - 1;
   db->flat = std::move(flat);
   db->off = std::move(off);
@@ -717,11 +757,22 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
       std::vector<ScoreUnit> units;
       build_units(db, W, S, ring_slots, max_wg, units, &db->units_chained);
       db->h_units = std::make_shared<const std::vector<ScoreUnit>>(units);
-      if (db->d_units) (void)hipFree(db->d_units);
-      db->d_units = nullptr;
-      if (hipMalloc(&db->d_units, std::max<size_t>(units.size(), 1) * sizeof(ScoreUnit)) != hipSuccess)
-        return fail(SW_E_NOMEM, "hipMalloc failed for the unit table");
-      HIPCK(hipMemcpy(db->d_units, units.data(), units.size() * sizeof(ScoreUnit), hipMemcpyHostToDevice));
+      if (db->borrowed) {
+        // (a pass of the previous geometry may still be reading the table: hipFree below waits for the whole device,
+        // here the context's stream is enough)
+        HIPCK(hipStreamSynchronize(c.stream));
+        int erc;
+        if ((erc = c.tdb.units.ensure(std::max<size_t>(units.size(), 1) * sizeof(ScoreUnit)))) return erc;
+        db->d_units = (ScoreUnit*)c.tdb.units.p;
+        HIPCK(hipMemcpyAsync(db->d_units, units.data(), units.size() * sizeof(ScoreUnit), hipMemcpyHostToDevice, c.stream));
+        HIPCK(hipStreamSynchronize(c.stream));
+      } else {
+        if (db->d_units) (void)hipFree(db->d_units);
+        db->d_units = nullptr;
+        if (hipMalloc(&db->d_units, std::max<size_t>(units.size(), 1) * sizeof(ScoreUnit)) != hipSuccess)
+          return fail(SW_E_NOMEM, "hipMalloc failed for the unit table");
+        HIPCK(hipMemcpy(db->d_units, units.data(), units.size() * sizeof(ScoreUnit), hipMemcpyHostToDevice));
+      }
       db->n_units = (uint32_t)units.size();
       db->units_S = S;
       db->units_R = ring_slots;
@@ -1284,6 +1335,10 @@ sw_db* swhip::db_create_owned(Context* ctx, std::string&& flat, std::vector<uint
   if (L.rc) return nullptr;
   return db_build(L.c, std::move(flat), std::move(off), known_acgt);
 }
+sw_db* swhip::db_create_temp_locked(Context& c, std::string&& flat, std::vector<uint64_t>&& off) {
+  return db_build(&c, std::move(flat), std::move(off), true, true);
+}
+void swhip::db_release_locked(sw_db* db) { db_release(db); }
 sw_db* swhip::db_open_on(Context* ctx, const char* path) {
   if (!path) {
     fail(SW_E_ARG, "null argument");

@@ -121,6 +121,10 @@ struct Context {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
   Workspace ws;
   Workspace ws2;  // second set for submissions in flight while the first is being read back (work packages)
+  struct {  // device arrays of the context's temporary database (sw_db.cpp: sw_db::borrowed)
+    DevBuf words, lens, slot_target, groups, elem_group, units;
+    bool busy = false;
+  } tdb;
   DevBuf sympool;  // the lane path's copy of a batch's symbol block (SymPool)
   hipEvent_t ev_pool = nullptr;  // ... uploaded (made on first use)
   // the allocation-free entry point (sw_db_scores_noalloc): windows of this device's copy of the static scratch
@@ -135,6 +139,11 @@ struct Context {
 // The context of a device (created on first use; device < 0: the process's default device, which sw_hip_init
 // selects and which is 0 otherwise).  On failure *out is null and the error is recorded.
 int ctx_get(int device, Context** out);
+// Lanes of a device: lane 0 is the device's context above; lanes 1 .. kMaxCtxLanes - 1 are auxiliary contexts (made on
+// first use) with a stream and workspaces of their own, so that independent latency-bound jobs of one call -- the
+// target sets of a combined batch of per-pair callers, sw_package.cpp -- run side by side on one GPU.
+constexpr unsigned kMaxCtxLanes = 8;
+int ctx_get_lane(int device, unsigned lane, Context** out);
 void reset_stats(Context& c);
 size_t noalloc_scratch_bytes();
 // Locks a context for one submission and makes its device current for the calling thread (HIP's current device
@@ -360,7 +369,7 @@ struct StageTimer {
     static const size_t v = getenv("SW_HIP_TRACE_MIN") ? (size_t)atoll(getenv("SW_HIP_TRACE_MIN")) : 1000;
     return v;
   }
-  explicit StageTimer(size_t n) : on(n >= min_pairs() && getenv("SW_HIP_TRACE")), t0(std::chrono::steady_clock::now()) {}
+  explicit StageTimer(size_t n) : on((n >= min_pairs() || n == 0) && getenv("SW_HIP_TRACE")), t0(std::chrono::steady_clock::now()) {}
   void lap(const char* what) {
     if (!on) return;
     const auto t1 = std::chrono::steady_clock::now();
@@ -428,6 +437,10 @@ int db_score_persist_end_locked(Context& c, sw_db* db, PersistPass& out);
 size_t db_persist_ring_bytes(const sw_db* db, uint32_t Q, int cus);
 sw_db* db_create_on(Context* ctx, const char* flat, const uint64_t* offsets, uint64_t n);
 sw_db* db_create_owned(Context* ctx, std::string&& flat, std::vector<uint64_t>&& off, bool known_acgt = false);
+// A temporary database of ACGT-only sequences on the device arrays of `c` (no hipMalloc / hipFree per database);
+// the caller holds c's lock from here until db_release_locked.
+sw_db* db_create_temp_locked(Context& c, std::string&& flat, std::vector<uint64_t>&& off);
+void db_release_locked(sw_db* db);
 std::string db_take_flat(sw_db* db);
 sw_db* db_open_on(Context* ctx, const char* path);  // a file written by sw_db_save
 const std::string& db_flat(const sw_db* db);

@@ -118,6 +118,8 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
   for (Workspace* w : wss)
     for (hipEvent_t* e : {&w->ev_k0, &w->ev_k1, &w->ev_done})
       if (!*e && hipEventCreate(e) != hipSuccess) return fail(SW_E_HIP, "hipEventCreate");
+  if (!c.stream2 && hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking) != hipSuccess)
+    return fail(SW_E_HIP, "hipStreamCreate");
 
   // The symbols: when the caller decoded the batch into one page-locked block (SymPool) that is no bigger than what
   // the slices would gather anyway, the block is uploaded ONCE, as it is, and a pair names its sequences by offset --

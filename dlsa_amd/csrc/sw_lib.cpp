@@ -102,7 +102,9 @@ std::mutex g_ctx_mu;  // creation of contexts and the default device
 Context* g_ctx[kMaxDevices] = {};
 int g_default_device = -1;
 
-int ctx_create(int device, Context** out) {
+// aux: an auxiliary context of the device (ctx_get_lane) -- a stream and workspaces of its own, no share of the static
+// scratch array (the allocation-free entry point runs on the device's first context only)
+int ctx_create(int device, Context** out, bool aux = false) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
@@ -130,12 +132,23 @@ int ctx_create(int device, Context** out) {
   c->device = device;
   c->cus = prop.multiProcessorCount;
   HIPCK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  HIPCK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
   HIPCK(hipEventCreate(&c->ev0));
   HIPCK(hipEventCreate(&c->ev1));
   HIPCK(hipEventCreate(&c->ev2));
   HIPCK(hipEventCreate(&c->ev3));
   if (const char* mb = getenv("SW_HIP_SCRATCH_MB")) c->scratch_budget = (size_t)atoll(mb) << 20;
+  if (aux) {
+    for (DevBuf* b : {&c->na.qwords, &c->na.ticket, &c->na.prog, &c->na.units, &c->na.slot_scores, &c->na.xin, &c->na.xzero,
+                      &c->na.xout, &c->na.xrecs, &c->na.gbound, &c->na.dirs, &c->na.sel_hist, &c->na.sel_ctr, &c->na.sel_rerun,
+                      &c->na.sel_cand, &c->na.sel_tie})
+      b->bind_fixed(nullptr, 0);
+    c->na.h_in.bind_fixed(nullptr, 0);
+    c->na.h_out.bind_fixed(nullptr, 0);
+    reset_stats(*c);
+    undo.c = nullptr;
+    *out = c.release();
+    return SW_OK;
+  }
   // this device's copy of the scratch array (the device is current: hipSetDevice above)
   void* ptr = nullptr;
   HIPCK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
@@ -189,6 +202,26 @@ int swhip::ctx_get(int device, Context** out) {
     if (rc) return rc;
   }
   *out = g_ctx[device];
+  return SW_OK;
+}
+namespace {
+Context* g_ctx_aux[kMaxDevices][kMaxCtxLanes - 1] = {};
+}
+int swhip::ctx_get_lane(int device, unsigned lane, Context** out) {
+  if (lane == 0) return ctx_get(device, out);
+  *out = nullptr;
+  if (lane >= kMaxCtxLanes) return fail(SW_E_ARG, "context lane out of range");
+  Context* first = nullptr;
+  const int rc0 = ctx_get(device, &first);  // (resolves a negative device, and makes sure the device is usable)
+  if (rc0) return rc0;
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  Context*& slot = g_ctx_aux[first->device][lane - 1];
+  if (!slot) {
+    const int rc = ctx_create(first->device, &slot, true);
+    if (rc) return rc;
+  }
+  slot->scratch_budget = first->scratch_budget;  // (follows sw_hip_set_scratch_mb; read when a job starts)
+  *out = slot;
   return SW_OK;
 }
 void swhip::reset_stats(Context& c) {
@@ -1088,6 +1121,19 @@ int swhip::align_many_on(int device, const char* const* queries, const char* con
   return align_interned(device, distinct.data(), distinct.size(), qi.data(), ti.data(), n, as, path, out);
 }
 
+namespace {
+// The per-pair host tables of one part of a package.  The parts of a package of millions of pairs use the same ones
+// one after the other: 80 MB of fresh vectors per part were 10 ms of page faults and constructors each time.
+struct PartTables {
+  std::vector<PairSpec> specs;
+  std::vector<size_t> idx;
+  std::vector<uint8_t> valid;
+  std::vector<PairOut> po;
+};
+int align_interned_part(int device, const char* const* distinct_p, size_t n_distinct, const uint32_t* qi, const uint32_t* ti,
+                        size_t n, AlignmentScores as, int path, Result** out, PartTables& tables);
+}  // namespace
+
 int swhip::align_interned(int device, const char* const* distinct_p, size_t n_distinct, const uint32_t* qi,
                           const uint32_t* ti, size_t n, AlignmentScores as, int path, Result** out) {
   if (n == 0) return SW_OK;
@@ -1096,13 +1142,18 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
   // A package of millions of pairs (C5's 1 000 x 10 000 reads) goes through in parts of 2^19 pairs: host tables,
   // the page-locked traceback arena and the device scratch stay what half a million pairs need, whatever n is.
   constexpr size_t kPart = (size_t)1 << 19;
-  if (n > kPart) {
-    for (size_t lo = 0; lo < n; lo += kPart) {
-      const int rc = align_interned(device, distinct_p, n_distinct, qi + lo, ti + lo, std::min(kPart, n - lo), as, path, out + lo);
-      if (rc) return rc;  // (the caller frees what earlier parts handed over)
-    }
-    return SW_OK;
+  PartTables tables;
+  for (size_t lo = 0; lo < n; lo += kPart) {
+    const int rc = align_interned_part(device, distinct_p, n_distinct, qi + lo, ti + lo, std::min(kPart, n - lo), as, path,
+                                       out + lo, tables);
+    if (rc) return rc;  // (the caller frees what earlier parts handed over)
   }
+  return SW_OK;
+}
+
+namespace {
+int align_interned_part(int device, const char* const* distinct_p, size_t n_distinct, const uint32_t* qi, const uint32_t* ti,
+                        size_t n, AlignmentScores as, int path, Result** out, PartTables& tables) {
   StageTimer tm(n);
   const Scoring sc = to_scoring(as);
   // only the sequences some pair names are decoded (a package may carry more)
@@ -1159,9 +1210,13 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
   });
   tm.lap("decode");
   // (filled in place on the host threads; pairs the reference would fail on are squeezed out afterwards -- rare)
-  std::vector<PairSpec> specs(n);
-  std::vector<size_t> idx(n);
-  std::vector<uint8_t> valid(n);  // 0: the pair fails as the reference's would; 1: valid; 3: valid and both ASCII
+  // (a table left by the previous part of the same package is reused as it is: every entry that counts is rewritten)
+  std::vector<PairSpec>& specs = tables.specs;
+  std::vector<size_t>& idx = tables.idx;
+  std::vector<uint8_t>& valid = tables.valid;  // 0: the pair fails as the reference's would; 1: valid; 3: valid and both ASCII
+  specs.resize(n);
+  idx.resize(n);
+  valid.resize(n);
   parallel_ranges(n, n * 64, [&](size_t lo, size_t hi) {
     for (size_t i = lo; i < hi; i++) {
       idx[i] = i;
@@ -1184,7 +1239,9 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
     idx.resize(w);
     valid.resize(w);
   }
-  std::vector<PairOut> po(specs.size());
+  std::vector<PairOut>& po = tables.po;
+  po.resize(specs.size());
+  parallel_ranges(po.size(), po.size() * 64, [&](size_t lo, size_t hi) { std::fill(po.begin() + (ptrdiff_t)lo, po.begin() + (ptrdiff_t)hi, PairOut{}); });
   ArenaLease lease;
   OpsArena& arena = lease.a;
   tm.lap("specs");
@@ -1484,6 +1541,7 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
   tm.lap("strings");
   return erc;
 }
+}  // namespace
 
 namespace {
 // ---- one pair per call, many callers: combining ---------------------------------------------------------------

@@ -20,12 +20,15 @@
 // That is the reference's own synthetic distribution (utils/generate_synthetic_data.py: queries 200-1000 nt against
 // targets of 10-200 kb).  Everything else takes the whole-matrix path of sw_lib.cpp.
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <cmath>
 #include <map>
 #include <mutex>
 #include <memory>
 #include <numeric>
+#include <string>
+#include <thread>
 
 #include "sw_host.h"
 
@@ -67,7 +70,13 @@ void flat_cache_put(std::string&& s) {
   std::lock_guard<std::mutex> lk(g_flat_mu);
   if (s.capacity() > g_flat_cache.capacity()) g_flat_cache.swap(s);
 }
-struct DbHolder {
+// a target set of at most this many residues is a job that leaves the GPU mostly idle (less than ~15 lane groups of
+// chunks): several of them run side by side
+constexpr uint64_t kSmallSetResidues = 4000000;
+// scoring << 1 | "the first windows of the last set mostly had to be continued" (run_job: wide_first)
+std::atomic<uint64_t> g_wide_hint{0};
+std::atomic<uint32_t> g_wide_probe{0};
+struct DbHolder {  // (of a temporary database: its maker holds the context's lock for the holder's whole life)
   sw_db* db = nullptr;
   ~DbHolder() {
     if (!db) return;
@@ -75,7 +84,7 @@ struct DbHolder {
       flat_cache_put(db_take_flat(db));
     } catch (...) {
     }
-    sw_db_free(db);
+    db_release_locked(db);
   }
 };
 
@@ -92,7 +101,7 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
   const size_t n = pair_q.size();
   handled.assign(n, 0);
   g_package_stats = PackageStats{};
-  StageTimer tm0(100000);
+  StageTimer tm0(getenv("SW_HIP_TRACE_LANES") ? 0 : 100000);
   static const bool disabled = getenv("SW_HIP_NO_WINDOWS") != nullptr;
   if (disabled || n == 0) return SW_OK;
   if (!(sc.match > 0 && sc.miss < 0 && sc.gap < 0 && sc.match <= 16384 && sc.miss >= -16384 && sc.gap >= -16384)) return SW_OK;
@@ -138,6 +147,13 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
     tids.erase(std::unique(tids.begin(), tids.end()), tids.end());
     by_targets[tids].push_back(kv.first);
   }
+  // (4 context lanes: the hardware queues a process has by default -- streams beyond that share a queue and take
+  // turns; measured, 15 sets of one target: 1 lane 30.9 ms, 2 19.0, 3 15.2, 4 14.1, 8 15.5.  Merging the small sets
+  // into one database per lane, every query passing over all of its targets, was tried and is slower: 15.4 ms.)
+  static const unsigned max_lanes = [] {
+    const char* e = getenv("SW_HIP_PACKAGE_LANES");
+    return e ? (unsigned)std::min<long>(kMaxCtxLanes, std::max<long>(1, atol(e))) : 4u;
+  }();
   tm0.lap("  windows: target sets");
   // A set whose boundary ring (one slot per work unit: residues of the chunks x Q / 128 bytes) would not fit twice the
   // scratch budget is processed in SLICES of its targets, each a temporary database of its own, instead of being
@@ -179,7 +195,12 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
     }
     if (!cur.empty()) jobs.push_back(SetJob{std::move(cur), &set.second, true});
   }
-  for (SetJob& job : jobs) {
+  // One job: a temporary database of the set's chunks, a score pass per query, window rounds -- on context `ctx`
+  // (every buffer it uses belongs to that context), counters into `st`.  Jobs touch distinct pairs; the caller's
+  // arena is the one thing they share (arena_mu).
+  std::mutex arena_mu;
+  auto run_job = [&](SetJob& job, Context* ctx, PackageStats& st, StageTimer& tm0) -> int {
+    int rc = SW_OK;
     const std::vector<uint32_t>& tids = job.tids;
     const std::vector<uint32_t>& set_queries = *job.queries;
     struct LapAtExit {  // (declared before the database holder: reports the time of its release too)
@@ -235,7 +256,7 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
     std::vector<uint64_t> off(chunks.size() + 1, 0);
     size_t total = 0;
     for (const Chunk& c : chunks) total += c.len;
-    StageTimer tm(100000);
+    StageTimer tm(tm0.on ? 0 : 100000);
     flat.resize(total);
     for (size_t i = 0; i < chunks.size(); i++) off[i + 1] = off[i] + chunks[i].len;
     parallel_ranges(chunks.size(), total, [&](size_t lo, size_t hi) {
@@ -243,8 +264,11 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
         memcpy(&flat[off[i]], dec[chunks[i].tid].src + chunks[i].start, chunks[i].len);
     });
     tm.lap("  windows: chunks");
+    // The context stays locked for the whole set: its temporary database and both workspaces are in use.
+    CtxLock L(ctx);
+    if (L.rc) return L.rc;
     DbHolder holder;
-    holder.db = db_create_owned(ctx, std::move(flat), std::move(off), true);  // (the eligibility scan above vouches for ACGT)
+    holder.db = db_create_temp_locked(*L.c, std::move(flat), std::move(off));  // (the eligibility scan above vouches for ACGT)
     tm.lap("  windows: temp db");
     if (!holder.db) return SW_E_HIP;
     sw_db* db = holder.db;
@@ -253,12 +277,20 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
     // the linear regime) leave their first window almost always.  Once half of a query's windows needed a second
     // submission, the following queries of the set enter theirs far enough to the left right away (Q rows reach
     // ~1.5 Q columns): one submission per query instead of two, for about the same number of cells.
+    // ... and what the last set with the same scoring saw carries over to the next one (a combined batch of per-pair
+    // callers is many sets of one pair each: nothing to learn from inside a set).  A hint only: window sizes never
+    // change a result.
     static const bool no_wide = getenv("SW_HIP_NO_WIDE_WINDOWS") != nullptr;  // experiments
-    bool wide_first = false;
+    const uint64_t hint_key = ((uint64_t)(uint16_t)sc.match << 32) | ((uint64_t)(uint16_t)sc.miss << 16) | (uint16_t)sc.gap;
+    // (only for sets too small to learn from themselves; every 32nd of them starts narrow again and renews the hint)
+    size_t job_pairs = 0;
+    for (uint32_t qid : set_queries) job_pairs += by_query.at(qid).size();
+    bool wide_first = !no_wide && job_pairs < 8 && g_wide_hint.load(std::memory_order_relaxed) == (hint_key << 1 | 1) &&
+                      g_wide_probe.fetch_add(1, std::memory_order_relaxed) % 32 != 31;
     // TWO score passes in flight, on the context's two workspaces: while the host picks and submits the windows of
     // query i (small, latency-bound submissions), the GPU already runs the pass of query i + 1, queued before them.
     // A slot -- boundary ring, slot scores, per-strip maxima, their host copies -- is reused as soon as its query's
-    // windows are done.  The context stays locked for the whole set (both workspaces are in use).
+    // windows are done.
     struct Flight {
       PersistPass pp;  // (its host buffers serve every other query of the set)
       QueryPrep qp;
@@ -266,8 +298,6 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
       bool active = false;
     };
     Flight flights[2];
-    CtxLock L(ctx);
-    if (L.rc) return L.rc;
     StreamDrain drain(L.c->stream);  // (declared after the flights: an early return waits for the passes in flight first)
     size_t next_query = 0;
     static const bool no_overlap = getenv("SW_HIP_NO_PASS_OVERLAP") != nullptr;  // experiments: one pass at a time
@@ -305,9 +335,9 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
       const uint32_t Q = (uint32_t)q.sym.size();
       std::vector<size_t> pairs_of_slice;
       if (job.partial)
-        for (size_t k : by_query[qid])
+        for (size_t k : by_query.at(qid))
           if (std::binary_search(tids.begin(), tids.end(), pair_t[k])) pairs_of_slice.push_back(k);
-      const std::vector<size_t>& pairs = job.partial ? pairs_of_slice : by_query[qid];
+      const std::vector<size_t>& pairs = job.partial ? pairs_of_slice : by_query.at(qid);
       if ((rc = db_score_persist_end_locked(*L.c, db, pp))) return rc;
       st.queries++;
       if (tm.on) fprintf(stderr, "[sw_hip]   windows: score kernel %.3f ms (Q = %u)\n", L.c->stats.score_kernel_ms, Q);
@@ -366,10 +396,13 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
             if (e - std::max(units[u].first_elem, G.strip_base) < kNearStrips && units[u].first_elem > G.strip_base &&
                 units[u].dep != UINT32_MAX)
               entry = units[u].dep;
-            if (wide_first)
-              for (uint32_t more = std::min<uint32_t>((Q + Q / 2) / (kScoreR * 16) + 1, 64);
-                   more > 0 && units[entry].first_elem > G.strip_base && units[entry].dep != UINT32_MAX; more--)
+            if (wide_first) {  // (in strips, not units: a unit is as many strips as the pass has waves per workgroup)
+              const uint32_t need = std::min<uint32_t>((Q + Q / 2) / kScoreR + 1, 64 * 16);
+              for (uint32_t have = 0; have < need && units[entry].first_elem > G.strip_base && units[entry].dep != UINT32_MAX;) {
                 entry = units[entry].dep;
+                have += units[entry].count;
+              }
+            }
             const uint32_t first = std::max(units[entry].first_elem, G.strip_base);
             const uint32_t col0 = (first - G.strip_base) * kScoreR;
             const uint32_t cols = std::min(C.len, (st_ + 1) * kScoreR) - col0;
@@ -468,10 +501,12 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
             // path that has left its first window runs on diagonally to the top of the matrix (x rows left ~ 1.5 x
             // columns at most), so the second submission is normally the last.
             uint32_t up = units[wins[w].unit].dep;
-            const uint32_t by_rows = (o.end_x + o.end_x / 2) / (kScoreR * 16) + 1;
-            for (uint32_t more = std::max<uint32_t>((1u << std::min<uint32_t>(round_no + 1, 4)) - 1, std::min<uint32_t>(by_rows, 64));
-                 more > 0 && units[up].first_elem > G.strip_base && units[up].dep != UINT32_MAX; more--)
+            const uint32_t by_rows = (o.end_x + o.end_x / 2) / kScoreR + 1;  // strips
+            const uint32_t need = std::max<uint32_t>(((1u << std::min<uint32_t>(round_no + 1, 4)) - 1) * 16, std::min<uint32_t>(by_rows, 64 * 16));
+            for (uint32_t have = units[up].count; have < need && units[up].first_elem > G.strip_base && units[up].dep != UINT32_MAX;) {
               up = units[up].dep;
+              have += units[up].count;
+            }
             const uint32_t first = std::max(units[up].first_elem, G.strip_base);
             const uint32_t col0 = (first - G.strip_base) * kScoreR;
             next.push_back(Win{pi, wins[w].chunk, up, col0, wins[w].col0 - col0});
@@ -482,8 +517,12 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
             T_.done = true;
           }
         }
-        if (tm.on) fprintf(stderr, "[sw_hip]   windows: round %u: %zu windows, %zu continue\n", round_no, wins.size(), next.size());
+        if (tm.on)
+          fprintf(stderr, "[sw_hip]   windows: round %u: %zu windows (first: %u rows x %u columns%s), %zu continue\n", round_no,
+                  wins.size(), specs[0].Q, specs[0].T, wide_first ? ", wide" : "", next.size());
         if (first_round && !no_wide && 2 * next.size() >= wins.size() && wins.size() >= 8) wide_first = true;
+        if (first_round && !no_wide && !wide_first)
+          g_wide_hint.store(hint_key << 1 | (2 * next.size() >= wins.size() ? 1 : 0), std::memory_order_relaxed);
         wins.swap(next);
         first_round = false;
         round_no++;
@@ -498,16 +537,91 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
         o.score = want[pi];
         o.bx = T_.bx;
         o.bj = T_.bj;
-        o.ops_off = arena.size();
         o.nops = (uint32_t)T_.ops.size();
-        arena.insert(arena.end(), T_.ops.begin(), T_.ops.end());
+        {
+          std::lock_guard<std::mutex> lk(arena_mu);
+          o.ops_off = arena.size();
+          arena.insert(arena.end(), T_.ops.begin(), T_.ops.end());
+        }
         po[k] = o;
         handled[k] = 1;
         st.pairs++;
       }
       if ((rc = start(cur))) return rc;  // the slot is free: the next query's pass goes behind whatever is queued
     }
+    return SW_OK;
+  };
+  // A combined batch of per-pair callers (15 goroutines, each with a query and a target of its own:
+  // worker_impl.go:204-238) is as many sets of ONE target with ONE query: every job is ~2 ms of pure latency -- a
+  // database build, one score pass that is a single chain of strips, a few window submissions -- with the GPU nearly
+  // idle.  Such jobs run side by side, each on a context lane of its own (stream + workspaces + temporary database);
+  // a set that fills the GPU by itself (a package's queries x hundreds of targets) runs alone on the device's
+  // context, as before.
+  size_t small_jobs = 0;
+  for (const SetJob& job : jobs) {
+    uint64_t residues = 0;
+    for (uint32_t t : job.tids) residues += dec[t].sym.size();
+    small_jobs += residues <= kSmallSetResidues;
   }
+  const unsigned lanes = small_jobs == jobs.size() ? (unsigned)std::min<size_t>(max_lanes, jobs.size()) : 1;
+  if (lanes <= 1) {
+    for (SetJob& job : jobs)
+      if ((rc = run_job(job, ctx, st, tm0))) return rc;
+    g_package_stats = st;
+    return SW_OK;
+  }
+  std::atomic<size_t> next_job{0};
+  const auto t_call = std::chrono::steady_clock::now();
+  std::mutex res_mu;
+  int first_rc = SW_OK;
+  std::string first_err;
+  auto lane_main = [&](unsigned lane) noexcept {
+    PackageStats mine{};
+    StageTimer tm_lane(getenv("SW_HIP_TRACE_LANES") ? 0 : SIZE_MAX);  // (off: the laps of concurrent jobs interleave)
+    int lrc = SW_OK;
+    std::string lerr;
+    try {
+      Context* lctx = nullptr;
+      lrc = ctx_get_lane(ctx->device, lane, &lctx);
+      while (!lrc) {
+        {
+          std::lock_guard<std::mutex> lk(res_mu);
+          if (first_rc) break;  // another lane failed: the call fails, nothing more to do
+        }
+        const size_t j = next_job.fetch_add(1);
+        if (j >= jobs.size()) break;
+        const auto t_a = std::chrono::steady_clock::now();
+        lrc = run_job(jobs[j], lctx, mine, tm_lane);
+        if (tm0.on) {
+          const auto t_b = std::chrono::steady_clock::now();
+          fprintf(stderr, "[sw_hip]   windows: lane %u job %zu: %.3f .. %.3f ms\n", lane, j,
+                  std::chrono::duration<double, std::milli>(t_a - t_call).count(),
+                  std::chrono::duration<double, std::milli>(t_b - t_call).count());
+        }
+      }
+      if (lrc) lerr = last_error_string();
+    } catch (...) {
+      lrc = SW_E_NOMEM;
+      lerr = "out of host memory";
+    }
+    std::lock_guard<std::mutex> lk(res_mu);
+    if (lrc && !first_rc) first_rc = lrc, first_err.swap(lerr);
+    st.pairs += mine.pairs, st.queries += mine.queries, st.windows += mine.windows, st.rounds += mine.rounds;
+    st.window_cells += mine.window_cells, st.chunks += mine.chunks, st.chunk_escapes += mine.chunk_escapes;
+  };
+  {
+    std::vector<std::thread> helpers;
+    for (unsigned lane = 1; lane < lanes; lane++) {
+      try {
+        helpers.emplace_back(lane_main, lane);
+      } catch (...) {
+        break;  // no thread to be had: the lanes that exist take the jobs
+      }
+    }
+    lane_main(0);
+    for (std::thread& t : helpers) t.join();
+  }
+  if (first_rc) return fail(first_rc, first_err);
   g_package_stats = st;
   return SW_OK;
 }

@@ -124,3 +124,34 @@ def test_package_beyond_the_ring_budget_is_sliced_not_dropped(oracle):
     assert [key(r) for r in res] == [key(r) for r in whole]
     for i in (3, 317, 400 + 3, 400 + 317, 11, 799):
         _check(oracle, res[i], qs[i], ts[i])
+
+
+def test_many_small_sets_run_side_by_side_on_context_lanes(oracle):
+    """What a combined batch of per-pair callers looks like (worker_impl.go:204-238: every goroutine brings a query and
+    a target of its own): as many target sets of one target as there are pairs.  The sets run side by side on the
+    device, each on a context lane of its own; every pair still gets exactly the oracle's record --
+    homologs that cross windows, a duplicated fragment, a pair whose query is another pair's query, a pair with no
+    hit."""
+    import dlsa_amd
+    from dlsa_amd import bridge
+    rng = random.Random(43)
+    s = dlsa_amd.AlignmentScore(SC[1], SC[2], SC[0])
+    qs = [_rnd(rng, rng.randint(200, 1000)) for _ in range(13)]
+    ts = [_rnd(rng, rng.randint(10000, 60000)) for _ in range(13)]
+    ts[0] = ts[0][:5000] + _mut(rng, qs[0], 0.05) + ts[0][5000:]                      # long alignment, several windows
+    ts[1] = ts[1][:300] + qs[1][10:150] + ts[1][300:7000] + qs[1][10:150] + ts[1][7000:]  # equal maxima
+    ts[2] = qs[2][:180] + ts[2]                                                      # at the very beginning
+    qs[3] = qs[4]                                                                    # the same query object twice
+    qs[5], ts[5] = "A" * 300, "C" * 12000                                            # no hit at all
+    res = bridge.align_batch(qs, ts, s, 0)
+    st = bridge.package_stats()
+    assert st["pairs"] == 13 and st["chunk_escapes"] == 0, st
+    assert st["queries"] in (12, 13), st      # one pass per set and query (the lanes' counters are summed); the
+                                              # query used twice is one set of two targets if the caller interned it
+    for r, q, t in zip(res, qs, ts):
+        _check(oracle, r, q, t)
+    # the same pairs one call at a time (one set, one lane) give the same records
+    for i in (0, 1, 5, 9):
+        one = bridge.align_batch([qs[i]], [ts[i]], s, 0)[0]
+        a, b = one, res[i]
+        assert (a.score, a.max_x, a.max_y, a.query, a.target) == (b.score, b.max_x, b.max_y, b.query, b.target)
