@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <mutex>
 #include <unordered_map>
 
 #include "sw_host.h"
@@ -27,8 +28,15 @@ int lanes_mode() {
 struct Elig {
   uint32_t k;     // index into specs
   uint32_t Q, T;  // rows, columns computed (Tlim)
+  uint32_t Tfull; // the target's length (statistics count the pair's whole matrix)
   bool row1_extra;  // the path also computes H(1, Tlim + 1) (T % 64 == 0 quirk): decided after the kernel
 };
+struct LanesScratch {
+  std::vector<Elig> cand, el;
+  std::vector<uint8_t> is_el;
+};
+std::mutex g_scratch_mu;
+LanesScratch g_scratch_kept;
 
 }  // namespace
 
@@ -40,8 +48,26 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
   if (!(sc.match > 0 && sc.miss < 0 && sc.gap < 0)) return SW_OK;
   StageTimer tm(n);
   // (on the host threads: a package of reads is 10^5 pairs)
-  std::vector<Elig> cand(n);
-  std::vector<uint8_t> is_el(n, 0);
+  // (the tables of a big batch are handed from call to call -- one set is kept -- instead of being page-faulted in
+  // afresh: 20 MB for a part of a package of reads)
+  struct ScratchLease {
+    LanesScratch t;
+    bool big;
+    explicit ScratchLease(bool big_) : big(big_) {
+      if (!big) return;
+      std::lock_guard<std::mutex> lk(g_scratch_mu);
+      std::swap(t, g_scratch_kept);
+    }
+    ~ScratchLease() {
+      if (!big || t.cand.capacity() > ((size_t)1 << 19)) return;
+      std::lock_guard<std::mutex> lk(g_scratch_mu);
+      if (t.cand.capacity() > g_scratch_kept.cand.capacity()) std::swap(t, g_scratch_kept);
+    }
+  } scratch(n >= 32768);
+  std::vector<Elig>& cand = scratch.t.cand;
+  std::vector<uint8_t>& is_el = scratch.t.is_el;
+  cand.resize(n);
+  is_el.assign(n, 0);
   // (for the choice between one upload of the caller's symbol block and per-slice staging, below)
   std::atomic<uint64_t> syms_unshared{0};
   std::atomic<bool> all_in_block{syms && syms->base && syms->syms};
@@ -57,7 +83,7 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
       if (pp.phaseQp || pp.straight || pp.Tlim == 0 || pp.T0 < pp.Tlim) continue;
       // V = H << 16 | tag must stay a non-negative int32
       if ((uint64_t)std::min(s.Q, pp.Tlim) * (uint64_t)sc.match > 32767u) continue;
-      cand[k] = Elig{(uint32_t)k, s.Q, pp.Tlim, pp.T0 > pp.Tlim};
+      cand[k] = Elig{(uint32_t)k, s.Q, pp.Tlim, s.T, pp.T0 > pp.Tlim};
       is_el[k] = 1;
       mine += (uint64_t)s.Q + s.T;
       if (syms && inside)
@@ -67,11 +93,11 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
     syms_unshared.fetch_add(mine);
     if (!inside) all_in_block.store(false);
   });
-  std::vector<Elig> el;
+  std::vector<Elig>& el = scratch.t.el;
+  el.clear();
   el.reserve(n);
   for (size_t k = 0; k < n; k++)
     if (is_el[k]) el.push_back(cand[k]);
-  std::vector<Elig>().swap(cand);
   if (el.empty()) return SW_OK;
   // length-sorted (rows, then columns, descending): the lanes of a wave run max rows x max strips of their group
   const bool sorted = std::is_sorted(el.begin(), el.end(), [](const Elig& a, const Elig& b) {
@@ -212,10 +238,10 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
     std::vector<uint64_t> stage_off(np + 1);
     {
       uint64_t at = 0;
-      for (size_t i = p0; i < p1; i++) {
+      for (size_t i = p0; i < p1; i++) {  // (el only: sequential memory)
         stage_off[i - p0] = at;
         at += (2 * ((uint64_t)el[i].Q + el[i].T) + 15) & ~(uint64_t)15;
-        sl.cells += (uint64_t)specs[el[i].k].Q * specs[el[i].k].T;
+        sl.cells += (uint64_t)el[i].Q * el[i].Tfull;
       }
       stage_off[np] = at;
     }
@@ -365,24 +391,35 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
     c.stats.exact_kernel_ms += ms;
     c.stats.lanes_kernel_ms += ms;
     const LaneOut* ho = (const LaneOut*)ws.h_out.p;
-    ks.clear();
-    for (size_t i = p0; i < p1; i++) {
-      const LaneOut& o = ho[i - p0];
-      // The path also computes H(1, Tlim + 1) <= match, a cell this kernel leaves out: it can only be the best
-      // cell if nothing scored above match.  Such a pair goes to the whole-matrix path.
-      if (el[i].row1_extra && o.score <= sc.match) continue;
-      PairOut& r = po[el[i].k];
-      r = PairOut{};
-      r.score = o.score;
-      r.bx = o.bxbj & 0xffffu;
-      r.bj = o.bxbj >> 16;
-      r.nops = o.nops;
-      r.ops_off = arena_base + sl.dense_base + (size_t)o.off16 * 16;
-      r.strings = 1;
-      r.key = o.score > 0 ? (((uint64_t)(r.bx + r.bj) << 31) | r.bx) : ~0ull;
-      handled[el[i].k] = 1;
-      ks.push_back(el[i].k);
-    }
+    // (on the host threads: the pairs of a slice are scattered over the caller's tables)
+    ks.resize(p1 - p0);
+    std::atomic<size_t> handed_back{0};
+    parallel_ranges(p1 - p0, (p1 - p0) * 128, [&](size_t lo, size_t hi) {
+      size_t back = 0;
+      for (size_t i = p0 + lo; i < p0 + hi; i++) {
+        const LaneOut& o = ho[i - p0];
+        // The path also computes H(1, Tlim + 1) <= match, a cell this kernel leaves out: it can only be the best
+        // cell if nothing scored above match.  Such a pair goes to the whole-matrix path.
+        if (el[i].row1_extra && o.score <= sc.match) {
+          ks[i - p0] = UINT32_MAX;
+          back++;
+          continue;
+        }
+        PairOut& r = po[el[i].k];
+        r = PairOut{};
+        r.score = o.score;
+        r.bx = o.bxbj & 0xffffu;
+        r.bj = o.bxbj >> 16;
+        r.nops = o.nops;
+        r.ops_off = arena_base + sl.dense_base + (size_t)o.off16 * 16;
+        r.strings = 1;
+        r.key = o.score > 0 ? (((uint64_t)(r.bx + r.bj) << 31) | r.bx) : ~0ull;
+        handled[el[i].k] = 1;
+        ks[i - p0] = el[i].k;
+      }
+      if (back) handed_back.fetch_add(back);
+    });
+    if (handed_back.load()) ks.erase(std::remove(ks.begin(), ks.end(), UINT32_MAX), ks.end());
     c.stats.exact_cells += sl.cells;
     c.stats.lanes_cells += sl.cells;
     c.stats.lanes_pairs += ks.size();

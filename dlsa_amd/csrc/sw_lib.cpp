@@ -814,10 +814,14 @@ struct ResultBox {
 constexpr uint32_t kMagic = 0x53574850u;  // "SWHP"
 // A worker produces one slab per work package and frees it before the next one arrives; a block of tens of
 // megabytes goes back to the kernel on free() and comes back as fresh zero pages (one page fault per 4 KiB while the
-// strings are written).  The last few released slabs are therefore kept for the next batch of a similar size: at
-// most kSlabCacheSlots blocks of at most kSlabCacheMax bytes each stay allocated (SW_HIP_NO_SLAB_CACHE=1: none).
-constexpr size_t kSlabCacheSlots = 4, kSlabCacheMin = (size_t)1 << 20, kSlabCacheMax = (size_t)256 << 20;
+// strings are written).  The last released slabs are therefore kept for the next batch of a similar size: at most
+// kSlabCacheSlots blocks of at most kSlabCacheMax bytes each and kSlabCacheTotal bytes together stay allocated
+// (SW_HIP_NO_SLAB_CACHE=1: none).  A package of a million read pairs is ~30 slabs of ~6 MB, one per slice of the lane
+// path (sw_lanes.cpp): with four slots most of them were page-faulted in again on every package.
+constexpr size_t kSlabCacheSlots = 32, kSlabCacheMin = (size_t)1 << 20, kSlabCacheMax = (size_t)256 << 20,
+                 kSlabCacheTotal = (size_t)1 << 30;
 std::atomic<Slab*> g_slab_cache[kSlabCacheSlots];
+std::atomic<size_t> g_slab_cache_bytes{0};
 bool slab_cache_enabled() {
   static const bool on = getenv("SW_HIP_NO_SLAB_CACHE") == nullptr;
   return on;
@@ -827,9 +831,15 @@ Slab* slab_alloc(size_t bytes) {
     for (auto& slot : g_slab_cache) {
       Slab* s = slot.exchange(nullptr, std::memory_order_acq_rel);
       if (!s) continue;
-      if (s->capacity >= bytes && s->capacity / 2 <= bytes) return s;
+      if (s->capacity >= bytes && s->capacity / 2 <= bytes) {
+        g_slab_cache_bytes.fetch_sub(s->capacity, std::memory_order_relaxed);
+        return s;
+      }
       Slab* expected = nullptr;  // not a fit: put it back (or drop it if the slot was taken meanwhile)
-      if (!slot.compare_exchange_strong(expected, s, std::memory_order_acq_rel)) free(s);
+      if (!slot.compare_exchange_strong(expected, s, std::memory_order_acq_rel)) {
+        g_slab_cache_bytes.fetch_sub(s->capacity, std::memory_order_relaxed);
+        free(s);
+      }
     }
   }
   const size_t cap = bytes + bytes / 8;  // (a package of the same shape next time fits although its strings differ)
@@ -838,14 +848,19 @@ Slab* slab_alloc(size_t bytes) {
   return s;
 }
 void slab_free(Slab* s) {
-  if (s->capacity >= kSlabCacheMin && s->capacity <= kSlabCacheMax + kSlabCacheMax / 8 && slab_cache_enabled()) {
+  if (s->capacity >= kSlabCacheMin && s->capacity <= kSlabCacheMax + kSlabCacheMax / 8 && slab_cache_enabled() &&
+      g_slab_cache_bytes.load(std::memory_order_relaxed) + s->capacity <= kSlabCacheTotal) {
+    g_slab_cache_bytes.fetch_add(s->capacity, std::memory_order_relaxed);  // (the budget may be overshot by a racing free: by one slab)
     for (auto& slot : g_slab_cache) {
       Slab* expected = nullptr;
       if (slot.compare_exchange_strong(expected, s, std::memory_order_acq_rel)) return;
     }
     // all slots taken: replace the first (the oldest habits of the caller change slowly; any policy does)
     Slab* old = g_slab_cache[0].exchange(s, std::memory_order_acq_rel);
-    if (old) free(old);
+    if (old) {
+      g_slab_cache_bytes.fetch_sub(old->capacity, std::memory_order_relaxed);
+      free(old);
+    }
     return;
   }
   free(s);
@@ -1132,6 +1147,8 @@ struct PartTables {
 };
 int align_interned_part(int device, const char* const* distinct_p, size_t n_distinct, const uint32_t* qi, const uint32_t* ti,
                         size_t n, AlignmentScores as, int path, Result** out, PartTables& tables);
+std::mutex g_tables_mu;
+PartTables g_tables_kept;
 }  // namespace
 
 int swhip::align_interned(int device, const char* const* distinct_p, size_t n_distinct, const uint32_t* qi,
@@ -1142,10 +1159,24 @@ int swhip::align_interned(int device, const char* const* distinct_p, size_t n_di
   // A package of millions of pairs (C5's 1 000 x 10 000 reads) goes through in parts of 2^19 pairs: host tables,
   // the page-locked traceback arena and the device scratch stay what half a million pairs need, whatever n is.
   constexpr size_t kPart = (size_t)1 << 19;
-  PartTables tables;
+  // (... and a worker's next package takes the tables of the last one: one set is kept, like the arenas)
+  struct TablesLease {
+    PartTables t;
+    bool big;
+    explicit TablesLease(bool big_) : big(big_) {
+      if (!big) return;
+      std::lock_guard<std::mutex> lk(g_tables_mu);
+      std::swap(t, g_tables_kept);
+    }
+    ~TablesLease() {
+      if (!big || t.specs.capacity() > kPart) return;
+      std::lock_guard<std::mutex> lk(g_tables_mu);
+      if (t.specs.capacity() > g_tables_kept.specs.capacity()) std::swap(t, g_tables_kept);
+    }
+  } lease(n >= 32768);
   for (size_t lo = 0; lo < n; lo += kPart) {
     const int rc = align_interned_part(device, distinct_p, n_distinct, qi + lo, ti + lo, std::min(kPart, n - lo), as, path,
-                                       out + lo, tables);
+                                       out + lo, lease.t);
     if (rc) return rc;  // (the caller frees what earlier parts handed over)
   }
   return SW_OK;
@@ -1262,6 +1293,9 @@ int align_interned_part(int device, const char* const* distinct_p, size_t n_dist
   // StrHdr + target alignment + NUL].  ASCII pairs (the normal case) know their string lengths up front (= the
   // number of traceback ops); a pair with non-ASCII symbols re-encodes to UTF-8 and keeps heap strings of its own.
   // (ks: the pairs as a list of indices into specs; nullptr: the range [k_lo, k_hi))
+  std::vector<uint8_t> ascii_of(valid.size());  // per pair: both sequences ASCII (valid[k] bit 1)
+  for (size_t k = 0; k < valid.size(); k++) ascii_of[k] = valid[k] >> 1;
+  auto pair_ascii = [&](size_t k) -> bool { return ascii_of[k] != 0; };
   auto emit_list = [&](const uint32_t* ks, size_t k_lo, size_t m, const OpsArena& ar) -> int {
     if (m == 0) return SW_OK;
     auto k_of = [&](size_t kk) -> size_t { return ks ? ks[kk] : k_lo + kk; };
@@ -1270,9 +1304,10 @@ int align_interned_part(int device, const char* const* distinct_p, size_t n_dist
     const size_t boxes_off = round8(sizeof(Slab));
     size_t bytes = boxes_off + m * sizeof(ResultBox);
     for (size_t kk = 0; kk < m; kk++) {
-      const size_t k = k_of(kk), i = idx[k];
+      const size_t k = k_of(kk);
       str_off[kk] = bytes;
-      if (dec[qi[i]].ascii && dec[ti[i]].ascii) bytes += 2 * (sizeof(StrHdr) + round8((size_t)po[k].nops + 1));
+      // (valid[k] bit 1: both sequences ASCII -- set with the pair's spec; not the three lookups through dec[])
+      if (pair_ascii(k)) bytes += 2 * (sizeof(StrHdr) + round8((size_t)po[k].nops + 1));
     }
     str_off[m] = bytes;
     Slab* slab = slab_alloc(bytes);
@@ -1286,19 +1321,31 @@ int align_interned_part(int device, const char* const* distinct_p, size_t n_dist
         const size_t k = k_of(kk), i = idx[k];
         ResultBox* b = boxes + kk;
         memset(b, 0, sizeof(ResultBox));
-        const Decoded &q = dec[qi[i]], &t = dec[ti[i]];
         const PairOut& o = po[k];
         const uint8_t* ops = ar.data() + o.ops_off;
+        if (o.strings) {  // the lane kernel wrote the strings themselves (sw_lanes.hip; ASCII pairs only)
+          const size_t each = sizeof(StrHdr) + round8((size_t)o.nops + 1);
+          StrHdr* hq = (StrHdr*)((char*)slab + str_off[kk]);
+          StrHdr* ht = (StrHdr*)((char*)slab + str_off[kk] + each);
+          hq->magic = ht->magic = kStrMagicSlab;
+          char *qa = (char*)(hq + 1), *ta = (char*)(ht + 1);
+          memcpy(qa, ops, o.nops);
+          memcpy(ta, ops + (((size_t)o.nops + 3) & ~(size_t)3), o.nops);
+          qa[o.nops] = ta[o.nops] = 0;
+          b->slab = slab;
+          box_fill(b, qa, ta, path, o);
+          mine += 3;
+          out[i] = &b->r;
+          continue;
+        }
+        const Decoded &q = dec[qi[i]], &t = dec[ti[i]];
         if (q.ascii && t.ascii) {
           const size_t each = sizeof(StrHdr) + round8((size_t)o.nops + 1);
           StrHdr* hq = (StrHdr*)((char*)slab + str_off[kk]);
           StrHdr* ht = (StrHdr*)((char*)slab + str_off[kk] + each);
           hq->magic = ht->magic = kStrMagicSlab;
           char *qa = (char*)(hq + 1), *ta = (char*)(ht + 1);
-          if (o.strings) {  // the lane kernel wrote the strings themselves (sw_lanes.hip)
-            memcpy(qa, ops, o.nops);
-            memcpy(ta, ops + (((size_t)o.nops + 3) & ~(size_t)3), o.nops);
-          } else {
+          {
             uint32_t nx = 0, nj = 0;
             for (uint32_t c = 0; c < o.nops; c++) {
               nx += ops[c] != 2;
@@ -1341,8 +1388,7 @@ int align_interned_part(int device, const char* const* distinct_p, size_t n_dist
   // next slice runs (one slab per slice).
   std::vector<uint8_t> emitted;
   if (path != SW_PATH_STRAIGHT && !specs.empty()) {
-    std::vector<uint8_t>& small = valid;  // (per pair: bit 1 = both sequences ASCII)
-    for (uint8_t& v : small) v >>= 1;
+    const std::vector<uint8_t>& small = ascii_of;
     struct {
       std::mutex mu;
       std::condition_variable cv;
