@@ -1224,7 +1224,9 @@ int align_interned_part(int device, const char* const* distinct_p, size_t n_dist
   std::vector<uint16_t, NoInitAlloc<uint16_t>> sym_plain;
   std::unique_ptr<ArenaLease> sym_lease;
   uint16_t* sym_base = nullptr;
-  if (n >= 1024 && path != SW_PATH_STRAIGHT) {
+  // (only a batch the lane kernel can take as a whole: its pairs have Q + T < 65 000 and the block must stay a
+  // block that ArenaLease keeps -- the long targets of a package for the fast path would be 170 MB of it)
+  if (n >= 1024 && path != SW_PATH_STRAIGHT && longest < 65000 && total_bytes <= ((size_t)64 << 20)) {
     sym_lease.reset(new ArenaLease((total_bytes + 8) * 2));
     sym_lease->a.resize((total_bytes + 8) * 2);
     sym_base = (uint16_t*)sym_lease->a.data();
