@@ -46,7 +46,30 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
   if (mode == 0 || n == 0) return SW_OK;
   // the kernel's domain: sentinel cells lose only if every step off a match costs something
   if (!(sc.match > 0 && sc.miss < 0 && sc.gap < 0)) return SW_OK;
+  if (mode == 2 && n < 1024) return SW_OK;  // (the cost model never takes fewer than 1 024 eligible pairs)
   StageTimer tm(n);
+  CtxLock L(device);
+  if (L.rc) return L.rc;
+  Context& c = *L.c;
+  Workspace* wss[2] = {&c.ws, &c.ws2};
+  for (Workspace* w : wss)
+    for (hipEvent_t* e : {&w->ev_k0, &w->ev_k1, &w->ev_done})
+      if (!*e && hipEventCreate(e) != hipSuccess) return fail(SW_E_HIP, "hipEventCreate");
+  if (!c.stream2 && hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking) != hipSuccess)
+    return fail(SW_E_HIP, "hipStreamCreate");
+  if (!c.ev_pool && hipEventCreate(&c.ev_pool) != hipSuccess) return fail(SW_E_HIP, "hipEventCreate");
+  // A big batch's symbol block (SymPool, below) goes to the device right away: the copy -- 30 MB for 100 000 distinct
+  // reads -- runs while the host threads sort out which pairs are eligible.  (Should the batch not take the block
+  // after all, the copy was for nothing; the drain makes sure it is over before the caller's block goes away.)
+  StreamDrain drain_upload(c.stream);
+  bool uploaded = false;
+  if (syms && syms->base && syms->syms && n >= 32768 && syms->syms < 0x7fffff00u && syms->syms * 2 <= c.scratch_budget / 4) {
+    int erc;
+    if ((erc = c.sympool.ensure(syms->syms * 2 + 256))) return erc;
+    HIPCK(hipMemcpyAsync(c.sympool.p, syms->base, syms->syms * 2, hipMemcpyHostToDevice, c.stream));
+    HIPCK(hipEventRecord(c.ev_pool, c.stream));
+    uploaded = true;
+  }
   // (on the host threads: a package of reads is 10^5 pairs)
   // (the tables of a big batch are handed from call to call -- one set is kept -- instead of being page-faulted in
   // afresh: 20 MB for a part of a package of reads)
@@ -137,16 +160,6 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
   }
   tm.lap("lanes: eligible + sort");
 
-  CtxLock L(device);
-  if (L.rc) return L.rc;
-  Context& c = *L.c;
-  Workspace* wss[2] = {&c.ws, &c.ws2};
-  for (Workspace* w : wss)
-    for (hipEvent_t* e : {&w->ev_k0, &w->ev_k1, &w->ev_done})
-      if (!*e && hipEventCreate(e) != hipSuccess) return fail(SW_E_HIP, "hipEventCreate");
-  if (!c.stream2 && hipStreamCreateWithFlags(&c.stream2, hipStreamNonBlocking) != hipSuccess)
-    return fail(SW_E_HIP, "hipStreamCreate");
-
   // The symbols: when the caller decoded the batch into one page-locked block (SymPool) that is no bigger than what
   // the slices would gather anyway, the block is uploaded ONCE, as it is, and a pair names its sequences by offset --
   // no per-slice gathering of distinct sequences, no staging copy.  Otherwise every slice stages its own pool.
@@ -154,10 +167,9 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
   // it at multiples of 8 symbols by construction -- a spec from elsewhere turns the choice off)
   const bool whole_pool = all_in_block.load() && syms->syms < 0x7fffff00u && syms->syms <= syms_unshared.load() &&
                           syms->syms * 2 <= c.scratch_budget / 4;
-  if (whole_pool) {
+  if (whole_pool && !uploaded) {
     int erc;
     if ((erc = c.sympool.ensure(syms->syms * 2 + 256))) return erc;
-    if (!c.ev_pool && hipEventCreate(&c.ev_pool) != hipSuccess) return fail(SW_E_HIP, "hipEventCreate");
   }
 
   // Slices of groups: each fits the scratch budget (direction words dominate: rows x strips x 256 bytes per group),
@@ -430,8 +442,10 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
   // (an error return must not leave copies in flight that write the arena or read h_in)
   StreamDrain drain(c.stream), drain2(c.stream2);
   if (whole_pool) {  // (both streams wait for it; the slices staged meanwhile queue behind it)
-    HIPCK(hipMemcpyAsync(c.sympool.p, syms->base, syms->syms * 2, hipMemcpyHostToDevice, c.stream));
-    HIPCK(hipEventRecord(c.ev_pool, c.stream));
+    if (!uploaded) {
+      HIPCK(hipMemcpyAsync(c.sympool.p, syms->base, syms->syms * 2, hipMemcpyHostToDevice, c.stream));
+      HIPCK(hipEventRecord(c.ev_pool, c.stream));
+    }
     HIPCK(hipStreamWaitEvent(c.stream2, c.ev_pool, 0));
   }
   double t_begin = 0, t_end = 0;  // (SW_HIP_TRACE: host time staging slices / waiting for and handing over slices)
@@ -455,6 +469,7 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
   if (rc) return rc;
   drain.dismiss();
   drain2.dismiss();
+  drain_upload.dismiss();
   tm.lap("lanes: submissions");
   (void)padded_cells;
   return SW_OK;
