@@ -181,6 +181,9 @@ struct LanesWork {
   unsigned long long wait_ticks;  // budget of a hand-over wait in s_memrealtime ticks (100 MHz)
   uint32_t n_groups;
   uint32_t n_units;       // sum of the groups' strips
+#ifdef SW_LANES_TIMELINE  // (development build, scratch/lanes_timeline.sh: when which strip ran, and how long it waited)
+  unsigned long long* timeline;  // per ticket: start, end, ticks spent waiting (s_memrealtime), hw id << 32 | unit
+#endif
 };
 hipError_t launch_lanes(const LanesWork& w, Scoring sc, bool want_trace, hipStream_t stream);
 

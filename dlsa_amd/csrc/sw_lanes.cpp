@@ -228,6 +228,10 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
   struct InFlight {
     size_t np = 0, ctl_at = 0;
     const uint8_t* d_dense = nullptr;
+#ifdef SW_LANES_TIMELINE
+    const unsigned long long* d_timeline = nullptr;
+    size_t n_units = 0;
+#endif
   } fl[2];
   // a slice has its stream: the copies of one overlap the kernels of the other
   hipStream_t streams[2] = {c.stream, c.stream2};
@@ -315,7 +319,12 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
     f.ctl_at = out_ops;
     uint8_t* const h_in = (uint8_t*)ws.h_in.p;
     lapse(1);
-    {  // tickets strip level by level: a strip's left neighbour always holds an earlier ticket
+    {
+      // Tickets strip level by level: a strip's left neighbour always holds an earlier ticket (no deadlock).  Measured
+      // against it on 8 000 x 1 kb (`scratch/lanes_timeline.sh`, `profiles/r03_lanes_timeline.txt`): the groups
+      // staggered (key = strip + group x strips / groups, so that the launch ends with the deep strips of the last
+      // groups only) 4.2 instead of 3.9 ms; issue priority (s_setprio) rising with the strip's depth 4.6, falling
+      // 3.9, high for a strip's first 64 rows 3.9.
       uint32_t* units = (uint32_t*)(h_in + in_units);
       uint32_t max_strips = 0;
       for (size_t g = sl.g0; g < sl.g1; g++) max_strips = std::max(max_strips, groups[g].nstrips);
@@ -374,6 +383,14 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
     w.outs = (LaneOut*)ws.xout.p;
     w.n_groups = (uint32_t)ng;
     f.d_dense = w.dense;
+#ifdef SW_LANES_TIMELINE
+    static DevBuf tl_buf[2];
+    if ((erc = tl_buf[si & 1].ensure(sl.n_units * 32 + 64))) return erc;
+    HIPCK(hipMemsetAsync(tl_buf[si & 1].p, 0, sl.n_units * 32, stream));
+    w.timeline = (unsigned long long*)tl_buf[si & 1].p;
+    f.d_timeline = w.timeline;
+    f.n_units = sl.n_units;
+#endif
     HIPCK(launch_lanes(w, sc, true, stream));
     HIPCK(hipEventRecord(ws.ev_k1, stream));
     HIPCK(hipMemcpyAsync(ws.h_out.p, ws.xout.p, np * sizeof(LaneOut), hipMemcpyDeviceToHost, stream));
@@ -398,6 +415,18 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
       HIPCK(hipMemcpyAsync(arena.data() + arena_base + sl.dense_base, f.d_dense, dense_used, hipMemcpyDeviceToHost, stream));
       HIPCK(hipStreamSynchronize(stream));
     }
+#ifdef SW_LANES_TIMELINE
+    if (const char* path = getenv("SW_LANES_TIMELINE_FILE")) {
+      std::vector<unsigned long long> tl(f.n_units * 4);
+      HIPCK(hipMemcpy(tl.data(), f.d_timeline, tl.size() * 8, hipMemcpyDeviceToHost));
+      if (FILE* fp = fopen(path, "ab")) {
+        const unsigned long long hdr[4] = {0x54494d454c494e45ull, f.n_units, si, 0};
+        fwrite(hdr, 8, 4, fp);
+        fwrite(tl.data(), 8, tl.size(), fp);
+        fclose(fp);
+      }
+    }
+#endif
     float ms = 0;
     HIPCK(hipEventElapsedTime(&ms, ws.ev_k0, ws.ev_k1));
     c.stats.exact_kernel_ms += ms;

@@ -140,6 +140,10 @@ __global__ void __launch_bounds__(64) sw_lanes_kernel(LanesWork W, int match, in
   const uint32_t tag_in = 0, tag_out = 0;
 #endif  // a word of the boundary column carries the strip that wrote it, + 1
   const unsigned long long deadline = __builtin_amdgcn_s_memrealtime() + W.wait_ticks;
+#ifdef SW_LANES_TIMELINE
+  const unsigned long long tl_start = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tl_wait = 0, tl_first = 0;
+#endif
 
   // the strip's 16 target symbols
   uint32_t t[16];
@@ -182,6 +186,9 @@ __global__ void __launch_bounds__(64) sw_lanes_kernel(LanesWork W, int match, in
         return __builtin_amdgcn_ballot_w64((bad & 0xffffu) != 0) != 0;
       };
       if (stale()) {
+#ifdef SW_LANES_TIMELINE
+        const unsigned long long tl_w0 = __builtin_amdgcn_s_memrealtime();
+#endif
         for (uint32_t spin = 0;; spin++) {
           if ((spin & 63u) == 63u) {  // (both conditions wave-uniform: s_endpgm must sit behind a scalar branch)
             const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(W.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -198,8 +205,14 @@ __global__ void __launch_bounds__(64) sw_lanes_kernel(LanesWork W, int match, in
           __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loads above (and everything older) have landed
           if (!stale()) break;
         }
+#ifdef SW_LANES_TIMELINE
+        tl_wait += __builtin_amdgcn_s_memrealtime() - tl_w0;
+#endif
       }
     }
+#ifdef SW_LANES_TIMELINE
+    if (rb == 0) tl_first = __builtin_amdgcn_s_memrealtime();
+#endif
     uint32_t hbc[RB];
 #pragma unroll
     for (int i = 0; i < RB; i++) hbc[i] = hbn[i] & 0xffff0000u;
@@ -243,6 +256,18 @@ __global__ void __launch_bounds__(64) sw_lanes_kernel(LanesWork W, int match, in
   rec.score = bestH;
   rec.key = bestkey;
   W.recs[((size_t)G.rec_off + s) * 64 + lane] = rec;
+#ifdef SW_LANES_TIMELINE
+  if (lane == 0 && W.timeline) {
+    uint32_t hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    unsigned long long* t = W.timeline + (size_t)ticket * 4;
+    t[0] = tl_start;
+    t[1] = __builtin_amdgcn_s_memrealtime();
+    t[2] = (tl_wait & 0xffffffffull) | ((tl_first - tl_start) << 32);  // (both well below 2^32 ticks of 10 ns)
+    t[3] = ((unsigned long long)((xcc & 0xfu) << 28 | (hw & 0x0fffffffu)) << 32) | unit;
+  }
+#endif
 }
 
 // Traceback: one LANE per pair follows the direction bits from the best cell until H reaches 0
