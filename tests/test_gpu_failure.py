@@ -41,3 +41,34 @@ def test_unpublished_boundary_is_reported_within_the_deadline(oracle):
         good.query, good.target, good.score, good.max_x, good.max_y)
     e = oracle.align("simd", q, t, -1, 2, -1)
     assert (again.query, again.target, again.score) == (e["q"], e["t"], e["score"] & 0xFFFF)
+
+
+def test_failure_on_a_context_lane_fails_the_batch_and_nothing_else(oracle):
+    """Many small target sets run side by side on context lanes (sw_package.cpp); a hand-over that never comes on
+    one of them must fail the whole batch with its message, leave no lane locked or busy, and the next batch must
+    give the same records as before."""
+    import dlsa_amd
+    from dlsa_amd import bridge
+    rng = random.Random(6)
+    r = lambda n: "".join(rng.choice("ACGT") for _ in range(n))  # noqa: E731
+    qs = [r(rng.randint(500, 900)) for _ in range(6)]
+    ts = [r(rng.randint(8000, 20000)) for _ in range(6)]
+    sc = dlsa_amd.AlignmentScore(2, -1, -1)
+    good = bridge.align_batch(qs, ts, sc, 0)
+    assert bridge.package_stats()["pairs"] == 6          # the fast path took them: six sets of one target
+    os.environ["SW_HIP_DEBUG_DROP_HANDOVER"] = "1"
+    os.environ["SW_HIP_EXACT_WAIT_MS"] = "300"
+    try:
+        t0 = time.perf_counter()
+        with pytest.raises(bridge.SwHipError) as ei:
+            bridge.align_batch(qs, ts, sc, 0)
+        assert "timed out" in str(ei.value) or "timed out" in bridge.last_error()
+        assert time.perf_counter() - t0 < 5.0
+    finally:
+        os.environ.pop("SW_HIP_DEBUG_DROP_HANDOVER", None)
+        os.environ.pop("SW_HIP_EXACT_WAIT_MS", None)
+    again = bridge.align_batch(qs, ts, sc, 0)
+    key = lambda x: (x.query, x.target, x.score, x.max_x, x.max_y)  # noqa: E731
+    assert [key(x) for x in again] == [key(x) for x in good]
+    e = oracle.align("lowmem", qs[2], ts[2], -1, 2, -1)
+    assert (again[2].query, again[2].target, again[2].score) == (e["q"], e["t"], e["score"] & 0xFFFF)
