@@ -163,9 +163,11 @@ int align_lanes(int device, const PairSpec* specs, size_t n, const uint8_t* smal
   // The symbols: when the caller decoded the batch into one page-locked block (SymPool) that is no bigger than what
   // the slices would gather anyway, the block is uploaded ONCE, as it is, and a pair names its sequences by offset --
   // no per-slice gathering of distinct sequences, no staging copy.  Otherwise every slice stages its own pool.
-  // (the block must not be more than staging without any sharing would copy; every eligible pair's sequences lie in
-  // it at multiples of 8 symbols by construction -- a spec from elsewhere turns the choice off)
-  const bool whole_pool = all_in_block.load() && syms->syms < 0x7fffff00u && syms->syms <= syms_unshared.load() &&
+  // (the block must not be much more than staging without any sharing would copy -- its sequences are padded to 8
+  // symbols, hence the quarter of slack; every eligible pair's sequences lie in it at multiples of 8 symbols by
+  // construction -- a spec from elsewhere turns the choice off)
+  const bool whole_pool = all_in_block.load() && syms->syms < 0x7fffff00u &&
+                          syms->syms <= syms_unshared.load() + syms_unshared.load() / 4 + 4096 &&
                           syms->syms * 2 <= c.scratch_budget / 4;
   if (whole_pool && !uploaded) {
     int erc;
