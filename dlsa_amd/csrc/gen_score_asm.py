@@ -213,12 +213,14 @@ def counts():
     return {"packed": packed, "packed_half": half, "snop": snop, "aux_x2": 0, "store": 0}
 
 
-def render(Dslots=3, B=12):
+def render(Dslots=3, B=12, Bsmall=6):
     """the text of sw_score_asm.inc (ring geometry must match sw_score.hip: D slots x B rows x 256 bytes per wave;
-    the asm text itself does not depend on them; B must be even)"""
+    the asm text itself does not depend on them; B must be even).  The unrolled block forms come twice: for blocks
+    of B rows (the throughput configuration) and, with the suffix _S, for blocks of Bsmall rows -- a small database
+    is a few chains of strips, and a chain advances one block at a time (sw_score.hip: score_block_rows)."""
     c = counts()
     out = ["// GENERATED by gen_score_asm.py -- do not edit.  Row loop of sw_score_kernel (gfx950).\n",
-           f"#define SW_SCORE_ASM_D {Dslots}\n#define SW_SCORE_ASM_B {B}\n",
+           f"#define SW_SCORE_ASM_D {Dslots}\n#define SW_SCORE_ASM_B {B}\n#define SW_SCORE_ASM_B_SMALL {Bsmall}\n",
            "// executed instructions per query row of one strip (wave-instructions; 16 columns x 128 targets):\n",
            f"#define SW_SCORE_ASM_PACKED_PER_ROW {c['packed']}   /* v_pk_* of one row body */\n",
            f"#define SW_SCORE_ASM_AUX_PER_2ROWS {c['aux_x2']}    /* other VALU per two rows (none: unrolled block, immediate offsets) */\n",
@@ -227,10 +229,12 @@ def render(Dslots=3, B=12):
            f"#define SW_SCORE_ASM_PACKED_PER_HALF_ROW {c['packed_half']}   /* ... of the half-width forms (8 columns) */\n",
            ]
     n = 0
-    for name, store, full, cols in (("SW_SCORE_ROWS_ASM", False, False, 16), ("SW_SCORE_ROWS_STORE_ASM", True, False, 16),
-                                    ("SW_SCORE_BLOCK_ASM", False, True, 16), ("SW_SCORE_BLOCK_STORE_ASM", True, True, 16),
-                                    ("SW_SCORE_ROWS_HALF_ASM", False, False, 8), ("SW_SCORE_BLOCK_HALF_ASM", False, True, 8)):
-        lines = generate_block(store, B, cols) if full else generate(store, cols)
+    for name, store, full, cols in (("SW_SCORE_ROWS_ASM", False, 0, 16), ("SW_SCORE_ROWS_STORE_ASM", True, 0, 16),
+                                    ("SW_SCORE_BLOCK_ASM", False, B, 16), ("SW_SCORE_BLOCK_STORE_ASM", True, B, 16),
+                                    ("SW_SCORE_ROWS_HALF_ASM", False, 0, 8), ("SW_SCORE_BLOCK_HALF_ASM", False, B, 8),
+                                    ("SW_SCORE_BLOCK_ASM_S", False, Bsmall, 16), ("SW_SCORE_BLOCK_STORE_ASM_S", True, Bsmall, 16),
+                                    ("SW_SCORE_BLOCK_HALF_ASM_S", False, Bsmall, 8)):
+        lines = generate_block(store, full, cols) if full else generate(store, cols)
         n += len(lines)
         out.append(f"#define {name} \\\n")
         for ln in lines:

@@ -720,15 +720,26 @@ struct ScoreBatch {
   uint32_t n_blocks, n_queries;
   uint64_t rows;            // sum of the query lengths
 };
+// qwords_small: the same query packed kScoreBSmall rows per word (QueryPrep::qwords_small); given it, a pass over a
+// small database runs with the small hand-over block (score_block_rows).  *block_rows_out: what the pass ran with.
 int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwords, size_t n_qwords, uint32_t Q,
                       Scoring sc, HostArena* arena = nullptr, bool persist = false, const ScoreBatch* batch = nullptr,
-                      hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr) {
+                      hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,
+                      const std::vector<uint32_t>* qwords_small = nullptr, int* block_rows_out = nullptr) {
   if (batch && (arena || persist || batch->n_blocks == 0 || n_qwords != (size_t)batch->n_blocks + 1))
     return fail(SW_E_ARG, "internal: bad query batch");
-  const uint32_t nblk = batch ? batch->n_blocks : (Q + kScoreB - 1) / kScoreB;
-  const uint32_t n_sets = batch ? batch->n_queries : 1;
-  const size_t Qpad = (size_t)nblk * kScoreB;
   const uint32_t W = (uint32_t)score_waves_per_group(db->n_elems, c.cus);
+  int BR = kScoreB;
+  if (!arena && !batch && qwords_small && score_block_rows((int)W, false) == kScoreBSmall) {
+    BR = kScoreBSmall;
+    qwords = qwords_small->data();
+    n_qwords = qwords_small->size();
+    if (n_qwords != (Q + (uint32_t)BR - 1) / (uint32_t)BR + 1) return fail(SW_E_ARG, "internal: bad query words");
+  }
+  if (block_rows_out) *block_rows_out = BR;
+  const uint32_t nblk = batch ? batch->n_blocks : (Q + (uint32_t)BR - 1) / (uint32_t)BR;
+  const uint32_t n_sets = batch ? batch->n_queries : 1;
+  const size_t Qpad = (size_t)nblk * (size_t)BR;
   uint32_t max_wg = (uint32_t)c.cus * (uint32_t)score_workgroups_per_cu((int)W);
   // Active lanes S of the ticket order (build_units): the unit that continues a group is handed out S tickets
   // after its producer.  With S beyond the number of resident workgroups the producer has FINISHED by then and the
@@ -856,7 +867,7 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
   if (const char* e = getenv("SW_HIP_SCORE_PUB")) p.pub = std::max(1, atoi(e));  // experiments
   // (the kernel's bracket: the context's pair of events, or the caller's when several passes are in flight)
   HIPCK(hipEventRecord(ev_begin ? ev_begin : c.ev0, c.stream));
-  HIPCK(launch_score(p, nwg, (int)W, c.stream));
+  HIPCK(launch_score(p, nwg, (int)W, BR, c.stream));
   HIPCK(hipEventRecord(ev_end ? ev_end : c.ev1, c.stream));
   // what this launch executes, for the roofline arithmetic of bench.py (counted, not pasted: every strip of the
   // stream walks all Q query rows through the generated row loop; a unit that hands its last column to the next
@@ -943,7 +954,8 @@ int db_scores_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, 
     rerun.resize(db->n);
     std::iota(rerun.begin(), rerun.end(), 0u);
   } else {
-    int rc = score_pass_locked(c, ws, db, qp.qwords.data(), qp.qwords.size(), (uint32_t)qp.d.sym.size(), sc);
+    int rc = score_pass_locked(c, ws, db, qp.qwords.data(), qp.qwords.size(), (uint32_t)qp.d.sym.size(), sc, nullptr, false,
+                               nullptr, nullptr, nullptr, &qp.qwords_small);
     if (rc) return rc;
     std::vector<int32_t> slot(db->slot_target.size());
     HIPCK(hipMemcpyAsync(slot.data(), ws.slot_scores.p, slot.size() * 4, hipMemcpyDeviceToHost, c.stream));
@@ -1064,7 +1076,8 @@ int db_topk_locked(Context& c, Workspace& ws, sw_db* db, const QueryPrep& qp, Sc
   bool device_done = false;
   std::vector<TopEntry> pool;
   if (device_topk(db, qp, sc, k)) {
-    int rc = score_pass_locked(c, ws, db, qp.qwords.data(), qp.qwords.size(), Q, sc);
+    int rc = score_pass_locked(c, ws, db, qp.qwords.data(), qp.qwords.size(), Q, sc, nullptr, false, nullptr, nullptr, nullptr,
+                               &qp.qwords_small);
     if (rc) return rc;
     if ((rc = select_pool_locked(c, ws, db, qp, sc, k, (const int32_t*)ws.slot_scores.p, Q, pool, device_done))) return rc;
     if (!device_done) {
@@ -1131,7 +1144,9 @@ int db_topk_multi_locked(Context& c, Workspace& ws, sw_db* db, const std::vector
 bool swhip::prep_query(const char* query, QueryPrep& qp) {
   if (!decode(query, qp.d)) return false;
   const size_t Q = qp.d.sym.size();
-  qp.qwords.assign((Q + kScoreB - 1) / kScoreB + 1, 0);  // one word per block of rows, 2 bits per row
+  // one word per block of rows, 2 bits per row, plus a padding word; for both block sizes of the score kernel
+  qp.qwords.assign((Q + kScoreB - 1) / kScoreB + 1, 0);
+  qp.qwords_small.assign((Q + kScoreBSmall - 1) / kScoreBSmall + 1, 0);
   for (size_t i = 0; i < Q; i++) {
     int code = qp.d.cp(i) < 128 ? nt_code((unsigned char)qp.d.cp(i)) : -1;
     if (code < 0) {
@@ -1139,6 +1154,7 @@ bool swhip::prep_query(const char* query, QueryPrep& qp) {
       code = 0;
     }
     qp.qwords[i / kScoreB] |= (uint32_t)code << (2 * (i % kScoreB));
+    qp.qwords_small[i / kScoreBSmall] |= (uint32_t)code << (2 * (i % kScoreBSmall));
   }
   return true;
 }
@@ -1159,7 +1175,9 @@ int swhip::db_score_persist_begin_locked(Context& c, Workspace& ws, sw_db* db, c
     HIPCK(hipEventCreate(&out.ev_k1));
     HIPCK(hipEventCreateWithFlags(&out.ev_done, hipEventDisableTiming));
   }
-  int rc = score_pass_locked(c, ws, db, qp.qwords.data(), qp.qwords.size(), Q, sc, nullptr, true, nullptr, out.ev_k0, out.ev_k1);
+  int block_rows = kScoreB;
+  int rc = score_pass_locked(c, ws, db, qp.qwords.data(), qp.qwords.size(), Q, sc, nullptr, true, nullptr, out.ev_k0, out.ev_k1,
+                             &qp.qwords_small, &block_rows);
   if (rc) return rc;
   const size_t slot_bytes = (db->slot_target.size() * 4 + 255) & ~(size_t)255, strip_bytes = (size_t)db->n_elems * 256;
   out.host.a.resize(slot_bytes + strip_bytes + 256);
@@ -1180,7 +1198,7 @@ int swhip::db_score_persist_begin_locked(Context& c, Workspace& ws, sw_db* db, c
   out.groups = &db->groups;
   out.slot_target = &db->slot_target;
   out.d_ring = (const uint32_t*)ws.gbound.p;
-  out.ring_stride = (size_t)((Q + kScoreB - 1) / kScoreB) * kScoreB * 64;
+  out.ring_stride = (size_t)((Q + (uint32_t)block_rows - 1) / (uint32_t)block_rows) * (size_t)block_rows * 64;
   out.n_elems = db->n_elems;
   return SW_OK;
 }

@@ -382,7 +382,8 @@ struct StageTimer {
 struct QueryPrep {
   Decoded d;
   bool acgt = true;
-  std::vector<uint32_t> qwords;
+  std::vector<uint32_t> qwords;        // 2 bits per row, kScoreB rows per word (+ a padding word)
+  std::vector<uint32_t> qwords_small;  // ... kScoreBSmall rows per word: passes over small databases (score_block_rows)
 };
 bool prep_query(const char* query, QueryPrep& qp);
 struct TopEntry {

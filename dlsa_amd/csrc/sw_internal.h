@@ -193,6 +193,10 @@ constexpr int kScoreR = 16;       // target columns per wave (one 2-bit packed d
 #define SW_SCORE_B 12
 #endif
 constexpr int kScoreB = SW_SCORE_B;       // query rows per hand-over block (one 2-bit packed dword of the query)
+// ... of a pass over a SMALL database (score_block_rows): a few chains of strips, each advancing one block at a time,
+// are bound by the block's latency, not by its overhead (one pair of the reference's synthetic default through the
+// work-package fast path: 1.94 -> 1.61 ms; the headline shape would lose 5 % to it)
+constexpr int kScoreBSmall = 6;
 constexpr int kGroupTargets = 128; // 64 lanes x 2 packed int16 halves
 
 // The packed database is one stream of STRIPS: all strips of group 0, then group 1, ...; strip e occupies
@@ -248,7 +252,10 @@ struct ScoreParams {
   uint32_t n_blocks;
 };
 enum : uint32_t { kBlkFirst = 16u, kBlkLast = 32u, kBlkQueryShift = 8u };
-hipError_t launch_score(const ScoreParams& p, int n_workgroups, int waves, hipStream_t stream);
+// block_rows: kScoreB, or kScoreBSmall (4-wave workgroups, one query only); the query words and the ring geometry
+// of the launch must have been made for it
+hipError_t launch_score(const ScoreParams& p, int n_workgroups, int waves, int block_rows, hipStream_t stream);
+int score_block_rows(int waves, bool multi);  // which of the two a pass of that shape runs with
 int score_waves_per_group(uint32_t total_strips, int cus);  // waves per workgroup for a database of that many strips
 int score_workgroups_per_cu(int waves);
 uint32_t score_queue_depth();  // units a workgroup may have in flight

@@ -314,9 +314,11 @@ int swhip::align_windows(const std::vector<Decoded>& dec, const std::vector<uint
         F.qp.d.sym = q.sym;
         F.qp.acgt = true;
         F.qp.qwords.assign((Q + kScoreB - 1) / kScoreB + 1, 0);
+        F.qp.qwords_small.assign((Q + kScoreBSmall - 1) / kScoreBSmall + 1, 0);
         for (uint32_t i = 0; i < Q; i++) {
           const uint32_t code = q.sym[i] == 'A' ? 0 : q.sym[i] == 'C' ? 1 : q.sym[i] == 'G' ? 2 : 3;
           F.qp.qwords[i / kScoreB] |= code << (2 * (i % kScoreB));
+          F.qp.qwords_small[i / kScoreBSmall] |= code << (2 * (i % kScoreBSmall));
         }
         const int rc2 = db_score_persist_begin_locked(*L.c, slot ? L.c->ws2 : L.c->ws, db, F.qp, sc, F.pp);
         if (rc2) return rc2;
