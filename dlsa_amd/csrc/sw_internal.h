@@ -196,7 +196,10 @@ constexpr int kScoreB = SW_SCORE_B;       // query rows per hand-over block (one
 // ... of a pass over a SMALL database (score_block_rows): a few chains of strips, each advancing one block at a time,
 // are bound by the block's latency, not by its overhead (one pair of the reference's synthetic default through the
 // work-package fast path: 1.94 -> 1.61 ms; the headline shape would lose 5 % to it)
-constexpr int kScoreBSmall = 6;
+#ifndef SW_SCORE_B_SMALL
+#define SW_SCORE_B_SMALL 6
+#endif
+constexpr int kScoreBSmall = SW_SCORE_B_SMALL;
 constexpr int kGroupTargets = 128; // 64 lanes x 2 packed int16 halves
 
 // The packed database is one stream of STRIPS: all strips of group 0, then group 1, ...; strip e occupies
