@@ -730,7 +730,7 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
     return fail(SW_E_ARG, "internal: bad query batch");
   const uint32_t W = (uint32_t)score_waves_per_group(db->n_elems, c.cus);
   int BR = kScoreB;
-  if (!arena && !batch && qwords_small && score_block_rows((int)W, false) == kScoreBSmall) {
+  if (!arena && !batch && qwords_small && score_block_rows((int)W, false, (uint32_t)db->groups.size()) == kScoreBSmall) {
     BR = kScoreBSmall;
     qwords = qwords_small->data();
     n_qwords = qwords_small->size();
