@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Opt-in fuzz on the GPU box, the work-package fast path: packages of a few queries x a few dozen long targets
 (homologs planted, with substitutions and indels, also near chunk and unit boundaries) through sw_align_batch against
-the oracle, every pair.  Usage: python3 scratch/fuzz_package.py [seed] [n_packages]"""
+the oracle, every pair.  Usage: python3 scratch/fuzz_package.py [seed] [n_packages] [sets]
+With `sets`: every pair of a batch has a query and a target of its own (what a combined batch of per-pair callers looks
+like): as many target sets of one target, which run side by side on the context lanes."""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -39,7 +41,14 @@ for it in range(n):
             p = rng.choice([0, max(0, T - len(frag)), rng.randint(0, T - 1), (rng.randint(1, max(1, T // 256)) * 256) % T])
             t = (t[:p] + frag + t[p + len(frag):])[:T]
         ts.append(t)
-    Qs = [q for q in qs for _ in ts]; Ts = ts * nq
+    if len(sys.argv) > 3 and sys.argv[3] == "sets":
+        Qs = [rng.choice(qs) if rng.random() < 0.3 else mutate(rng.choice(qs), 0.3, 0.1) + rnd(rng.randint(40, 200)) for _ in ts]
+        Qs = [q for q in Qs if len(q) >= 40] + qs[:max(0, len(ts) - len(Qs))]
+        Qs = (Qs * 2)[:len(ts)]
+        Qs = [str(q) + "" for q in Qs]  # (distinct objects: a query of its own per pair)
+        Ts = ts
+    else:
+        Qs = [q for q in qs for _ in ts]; Ts = ts * nq
     got = bridge.align_batch(Qs, Ts, dlsa_amd.AlignmentScore(match, miss, gap), 0)
     fast += bridge.package_stats()["pairs"]
     for q, t, g in zip(Qs, Ts, got):

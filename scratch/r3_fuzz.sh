@@ -17,5 +17,7 @@ timeout -k 10 170 python3 scratch/fuzz_long.py 321 600 >> $OUT 2>&1
 # (forced onto single long pairs the lane kernel runs one wave per pair: a few dozen are enough)
 SW_HIP_LANES=1 timeout -k 10 170 python3 scratch/fuzz_long.py 322 24 >> $OUT 2>&1
 timeout -k 10 170 python3 scratch/fuzz_package.py 331 40 >> $OUT 2>&1
+# (batches in which every pair has a target of its own: the context lanes of the fast path)
+timeout -k 10 170 python3 scratch/fuzz_package.py 351 60 sets >> $OUT 2>&1
 timeout -k 10 170 python3 scratch/fuzz_db.py 341 100 >> $OUT 2>&1
 echo "all fuzzers done" >> $OUT
