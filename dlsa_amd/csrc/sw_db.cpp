@@ -728,7 +728,7 @@ int score_pass_locked(Context& c, Workspace& ws, sw_db* db, const uint32_t* qwor
                       const std::vector<uint32_t>* qwords_small = nullptr, int* block_rows_out = nullptr) {
   if (batch && (arena || persist || batch->n_blocks == 0 || n_qwords != (size_t)batch->n_blocks + 1))
     return fail(SW_E_ARG, "internal: bad query batch");
-  const uint32_t W = (uint32_t)score_waves_per_group(db->n_elems, c.cus);
+  const uint32_t W = (uint32_t)score_waves_per_group(db->n_elems, c.cus, (uint32_t)db->groups.size());
   int BR = kScoreB;
   if (!arena && !batch && qwords_small && score_block_rows((int)W, false, (uint32_t)db->groups.size()) == kScoreBSmall) {
     BR = kScoreBSmall;
@@ -1213,7 +1213,7 @@ int swhip::db_score_persist_locked(Context& c, Workspace& ws, sw_db* db, const Q
   return db_score_persist_end_locked(c, db, out);
 }
 size_t swhip::db_persist_ring_bytes(const sw_db* db, uint32_t Q, int cus) {
-  const uint32_t W = (uint32_t)score_waves_per_group(db->n_elems, cus);
+  const uint32_t W = (uint32_t)score_waves_per_group(db->n_elems, cus, (uint32_t)db->groups.size());
   const size_t n_units = units_bound(db->n_elems, db->groups.size(), W, (uint32_t)cus * (uint32_t)score_workgroups_per_cu((int)W));
   return n_units * (size_t)((Q + kScoreB - 1) / kScoreB) * kScoreB * 256;
 }

@@ -259,7 +259,7 @@ enum : uint32_t { kBlkFirst = 16u, kBlkLast = 32u, kBlkQueryShift = 8u };
 // of the launch must have been made for it
 hipError_t launch_score(const ScoreParams& p, int n_workgroups, int waves, int block_rows, hipStream_t stream);
 int score_block_rows(int waves, bool multi, uint32_t n_groups);  // which of the two a pass of that shape runs with
-int score_waves_per_group(uint32_t total_strips, int cus);  // waves per workgroup for a database of that many strips
+int score_waves_per_group(uint32_t total_strips, int cus, uint32_t n_groups);  // waves per workgroup for a database of that many strips in that many lane groups
 int score_workgroups_per_cu(int waves);
 uint32_t score_queue_depth();  // units a workgroup may have in flight
 // instruction counts of the generated row loop (sw_score_asm.inc): packed VALU per row, address increments per 2 rows
