@@ -193,9 +193,10 @@ constexpr int kScoreR = 16;       // target columns per wave (one 2-bit packed d
 #define SW_SCORE_B 12
 #endif
 constexpr int kScoreB = SW_SCORE_B;       // query rows per hand-over block (one 2-bit packed dword of the query)
-// ... of a pass over a SMALL database (score_block_rows): a few chains of strips, each advancing one block at a time,
-// are bound by the block's latency, not by its overhead (one pair of the reference's synthetic default through the
-// work-package fast path: 1.94 -> 1.61 ms; the headline shape would lose 5 % to it)
+// ... of a pass with one query (score_block_rows; the ring is then twice as many blocks deep): finer hand-over, first
+// for passes over small databases, which are a few chains of strips bound by the block's latency (one pair of the
+// reference's synthetic default through the work-package fast path: 1.94 -> 1.61 ms), and since the waves set their
+// issue priority by their lead also for the throughput shapes (sw_score.hip)
 #ifndef SW_SCORE_B_SMALL
 #define SW_SCORE_B_SMALL 6
 #endif

@@ -18,11 +18,12 @@
 //    v_pk_max_i16, and the running maximum on every second column only (max(left,up) of an odd column
 //    covers the new even-column cell of this row and the odd-column cell of the previous row);
 //  * the W waves of a workgroup own consecutive 16-column strips and run as a software pipeline over
-//    blocks of B = 12 query rows; the H column between neighbouring strips travels through an LDS ring of
-//    D = 3 blocks per wave with ready/done flags in LDS -- no workgroup barrier in the main loop, so a wave
-//    that the issue arbiter favours runs ahead instead of parking the SIMD at a barrier.  (B x D: 16 x 2
-//    was 2.4 % slower on the bench shape and 5 % on 1 kb queries -- the ring's slack in rows and the
-//    hand-over granularity both count; 36 rows x 17 rings is what 160 KB of LDS holds);
+//    blocks of B query rows; the H column between neighbouring strips travels through an LDS ring of D blocks per
+//    wave with ready/done flags in LDS -- no workgroup barrier in the main loop, so a wave that the issue arbiter
+//    favours runs ahead instead of parking the SIMD at a barrier.  B x D = 6 x 6 for one query, 12 x 3 for a stacked
+//    batch of queries (36 rows x 17 rings is what 160 KB of LDS holds).  Before the waves set their own issue
+//    priority (see the block loop) 12 x 3 was the faster one by 4 %; with it the finer hand-over wins: bench shape
+//    67.3 -> 66.2 ms, 150-nt reads 16.5 -> 16.2 ms, 8 x 4 the same, 4 x 9 slower by 3-4 %;
 //  * a work unit is up to W consecutive strips of the database's strip stream (all strips of group 0, then
 //    group 1, ...) against the whole query.  Persistent workgroups (one per CU) pull units from an atomic
 //    ticket; when a group continues in the next unit the two run concurrently on different CUs as a chain:
@@ -68,6 +69,9 @@ static_assert(SW_SCORE_ASM_B == kScoreB && SW_SCORE_ASM_B_SMALL == kScoreBSmall,
 #define SW_SCORE_D SW_SCORE_ASM_D
 #endif
 constexpr int D = SW_SCORE_D;  // blocks of slack between neighbouring waves (ring depth)
+#ifndef SW_SCORE_D_SMALL
+#define SW_SCORE_D_SMALL (SW_SCORE_D * SW_SCORE_ASM_B / SW_SCORE_ASM_B_SMALL)  // the same rows of slack
+#endif
 
 __device__ __forceinline__ s2 pk_max(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
 __device__ __forceinline__ s2 as_s2(uint32_t v) { return __builtin_bit_cast(s2, v); }
@@ -110,11 +114,27 @@ __device__ __forceinline__ void spin_check(uint32_t spin, uint32_t code, uint32_
   if (__builtin_amdgcn_s_memrealtime() >= (((unsigned long long)dhi << 32) | dlo)) die(code, err);
 }
 
+#ifdef SW_SCORE_TIMELINE  // (development build, scratch/score_timeline.sh: where a wave's time goes, in 10 ns ticks)
+__device__ uint32_t g_score_tl[256 * 16 * 8];
+__device__ __forceinline__ uint32_t tl_now() { return (uint32_t)__builtin_amdgcn_s_memrealtime(); }
+struct TlAcc { uint32_t queue = 0, setup = 0, ready = 0, done = 0, glb = 0, strips = 0, tail = 0; };
+#define TL(...) __VA_ARGS__
+#else
+#define TL(...)
+#endif
+
 // Spin on a progress counter written by another workgroup (sc1 load = L1 bypass).
 __device__ __forceinline__ void wait_ge(const uint32_t* ctr, uint32_t need, uint32_t* err,
-                                        const unsigned long long* deadline) {
+                                        const unsigned long long* deadline TL(, uint32_t* acc = nullptr)) {
+#ifdef SW_SCORE_TIMELINE
+  if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return;
+  const uint32_t t0 = tl_now();
+#endif
   for (uint32_t spin = 0;; spin++) {
-    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return;
+    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) {
+      TL(if (acc) *acc += tl_now() - t0);
+      return;
+    }
     spin_check(spin, 1u, err, deadline);
     __builtin_amdgcn_s_sleep(SW_SCORE_GSLEEP);
   }
@@ -125,8 +145,8 @@ __device__ __forceinline__ void wait_ge(const uint32_t* ctr, uint32_t need, uint
 // drains them (vmcnt(0)) and only then adds to the counter, so no release fence is needed on its side.
 // Returns the number of published blocks.  Runs once per PUB blocks, not per block.
 __device__ __forceinline__ uint32_t acquire_blocks(const uint32_t* ctr, uint32_t need, uint32_t* err,
-                                                   const unsigned long long* deadline) {
-  wait_ge(ctr, need, err, deadline);
+                                                   const unsigned long long* deadline TL(, uint32_t* acc = nullptr)) {
+  wait_ge(ctr, need, err, deadline TL(, acc));
   const uint32_t v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -155,10 +175,18 @@ __device__ __forceinline__ void lds_flag_store(uint32_t* f, uint32_t v) {
 // spin on an LDS flag, bounded like wait_ge
 template <int SLEEP = SW_SCORE_LSLEEP>
 __device__ __forceinline__ void lds_wait_ge(const uint32_t* f, uint32_t need, uint32_t* err,
-                                            const unsigned long long* deadline) {
+                                            const unsigned long long* deadline TL(, uint32_t* acc = nullptr)) {
+#ifdef SW_SCORE_TIMELINE
+  if (lds_flag_load(f) >= need) {
+    asm volatile("" ::: "memory");
+    return;
+  }
+  const uint32_t t0 = tl_now();
+#endif
   for (uint32_t spin = 0;; spin++) {
     if (lds_flag_load(f) >= need) {
       asm volatile("" ::: "memory");
+      TL(if (acc) *acc += tl_now() - t0);
       return;
     }
     spin_check(spin, 2u, err, deadline);
@@ -170,6 +198,13 @@ __device__ __forceinline__ uint32_t lds_addr(const uint32_t* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint32_t*)p;
 }
 __device__ __forceinline__ int pk2(short lo, short hi) { return (int)(((uint32_t)(uint16_t)hi << 16) | (uint16_t)lo); }
+
+__device__ __forceinline__ void set_prio(int p) {  // wave-uniform
+  if (p >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (p == 2) __builtin_amdgcn_s_setprio(2);
+  else if (p == 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
 
 // units a workgroup's first wave may run ahead of its slowest wave (entries of the LDS unit queue)
 constexpr uint32_t QN = 8;
@@ -184,7 +219,9 @@ __global__ void __launch_bounds__(W * 64, W == 16 ? 4 : W == 8 ? 2 : 3) sw_score
   // H column entering each wave: [wave][slot][row][lane], D slots of B rows, written by the wave on its
   // left (wave 0: the previous unit's column, DMA'd from HBM).  Two rows of padding: the row loop
   // prefetches one row past the block it works on.  Ring W is written by the last wave and never read.
-  constexpr int RING = D * B * 64;  // dwords per wave
+  constexpr int DD = B == kScoreB ? D : SW_SCORE_D_SMALL;  // ring depth in blocks: the same rows of slack for either block size
+  static_assert(DD >= 2 && DD * B <= 36, "a wave's ring is DD * B rows of 256 bytes; 17 rings share 160 KB of LDS");
+  constexpr int RING = DD * B * 64;  // dwords per wave
   __shared__ uint32_t lds[(W + 1) * RING + 2 * 64];
   __shared__ uint32_t zeros[(B + 2) * 64];  // the H column left of a group's first strip: H(x, 0) = 0
   __shared__ uint32_t ready[W + 1];   // ready[w]: blocks written into wave w's input ring (cumulative over units)
@@ -223,8 +260,10 @@ __global__ void __launch_bounds__(W * 64, W == 16 ? 4 : W == 8 ? 2 : 3) sw_score
   // `base`: blocks of all earlier units of this workgroup; flags and ring slots count blocks cumulatively, so
   // a wave that finishes its strip goes straight on to the next unit while its right-hand neighbours drain.
   uint32_t base = 0;
+  TL(TlAcc tl; const uint32_t tl_begin = tl_now(); uint32_t tl_mark = tl_begin);
   for (uint32_t k = 0;; k++, base += nblk) {
     uint32_t unit;
+    TL(tl_mark = tl_now());
     if (wave == 0) {
       if (k >= QN) {  // the queue entry about to be overwritten has been read by every wave
         for (uint32_t spin = 0;; spin++) {
@@ -241,11 +280,12 @@ __global__ void __launch_bounds__(W * 64, W == 16 ? 4 : W == 8 ? 2 : 3) sw_score
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       lds_flag_store(&uq_cnt, k + 1);
     } else {
-      lds_wait_ge(&uq_cnt, k + 1, p.err, &deadline);
+      lds_wait_ge(&uq_cnt, k + 1, p.err, &deadline TL(, &tl.queue));
       unit = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_flag_load(&uq[k % QN]));
       lds_flag_store(&started[wave], k + 1);
     }
     if (unit >= p.n_units) break;
+    TL(tl.tail = tl_now() - tl_begin);  // (left at its last value: when this wave took its last real unit)
 
     // a unit is up to W consecutive strips of the database's strip stream
     const ScoreUnit U = p.units[unit];
@@ -320,11 +360,11 @@ __global__ void __launch_bounds__(W * 64, W == 16 ? 4 : W == 8 ? 2 : 3) sw_score
     uint32_t avail = 0;  // wave 0 of a chained unit: blocks of the producer's column known to be published
     if (glb_out && U.reuse != 0xffffffffu) {
       // the previous content of my output slot was read by ticket U.reuse: its wave 0 must be done with it
-      wait_ge(p.prog + 2 * (size_t)U.reuse + 1, 1, p.err, &deadline);
+      wait_ge(p.prog + 2 * (size_t)U.reuse + 1, 1, p.err, &deadline TL(, &tl.glb));
     }
     if (glb_in) {
-      avail = acquire_blocks(prog_in, 1, p.err, &deadline);
-      dma_block<B>(gin + lane, my_in_base + (base % D) * (B * 64));
+      avail = acquire_blocks(prog_in, 1, p.err, &deadline TL(, &tl.glb));
+      dma_block<B>(gin + lane, my_in_base + (base % DD) * (B * 64));
     }
     int diag = 0;
     uint32_t goff = (uint32_t)lane * 4u;
@@ -335,20 +375,46 @@ __global__ void __launch_bounds__(W * 64, W == 16 ? 4 : W == 8 ? 2 : 3) sw_score
     const uint32_t gout_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gout_u);
     const uint32_t gout_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(gout_u >> 32));
     const uint64_t gout_s = ((uint64_t)gout_hi << 32) | (uint64_t)gout_lo;
+#ifdef SW_SCORE_TIMELINE
+    {  // set-up ends when the tables are built: make the loads land before the clock is read
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      int sink = TQ[0][0] ^ TQ[R - 1][3];
+      asm volatile("" ::"v"(sink));
+      tl.setup += tl_now() - tl_mark;
+      tl.strips++;
+    }
+#endif
     for (uint32_t blk = 0; blk < nblk; blk++) {
       const uint32_t cb = base + blk;  // cumulative block number
-      const uint32_t slot = cb % D;
+      const uint32_t slot = cb % DD;
       if (glb_in) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS-DMA of this block has landed
         if (blk + 1 < nblk) {
-          if (avail < blk + 2) avail = acquire_blocks(prog_in, blk + 2, p.err, &deadline);
-          dma_block<B>(gin + (size_t)(blk + 1) * B * 64 + lane, my_in_base + ((cb + 1) % D) * (B * 64));
+          if (avail < blk + 2) avail = acquire_blocks(prog_in, blk + 2, p.err, &deadline TL(, &tl.glb));
+          dma_block<B>(gin + (size_t)(blk + 1) * B * 64 + lane, my_in_base + ((cb + 1) % DD) * (B * 64));
         }
       }
       // ---- wait for my input block and for room in my neighbour's ring
-      if (ring_in) lds_wait_ge<SW_SCORE_RSLEEP>(&ready[wave], cb + 1, p.err, &deadline);
-      if (lds_out && cb >= (uint32_t)D) lds_wait_ge<SW_SCORE_DSLEEP>(&done[wave + 1], cb + 1 - D, p.err, &deadline);
+      if (ring_in) lds_wait_ge<SW_SCORE_RSLEEP>(&ready[wave], cb + 1, p.err, &deadline TL(, &tl.ready));
+      if (lds_out && cb >= (uint32_t)DD) lds_wait_ge<SW_SCORE_DSLEEP>(&done[wave + 1], cb + 1 - DD, p.err, &deadline TL(, &tl.done));
 
+      // ---- issue priority for this block.  The SIMD serves its resident waves oldest first, so without a hint the
+      // low-numbered waves of a workgroup sprint until their output ring is full, stall, and leave their SIMD with
+      // three or two runnable waves -- and a SIMD issues the dependent packed chain of ONE wave at a third of its
+      // rate.  The wave whose right-hand neighbour has caught up with it (nothing pending in the ring: the neighbour
+      // is about to starve) is the one the pipeline waits for: it gets priority 3, a wave that is a full ring ahead
+      // priority 0, the last wave of the pipeline always 3.  (Measured with the per-wave clocks of
+      // scratch/score_timeline.sh, 150-nt reads: waiting for ring room 39 % of all wave time -> 14 %, for the left
+      // neighbour 5 % -> 21 %, kernel 17.8 -> 16.5 ms; bench shape 68.7 -> 67.1 ms.  A static priority rising with
+      // the wave index loses 2 %, variants that also weigh the input side gain nothing.)
+      if constexpr (W == 16) {
+        if (lds_out) {
+          const int lead = (int)(cb - (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_flag_load(&done[wave + 1])));
+          set_prio(3 - (lead > 0 ? (lead * 3 + DD - 1) / DD : 0));
+        } else {
+          set_prio(3);
+        }
+      }
       uint32_t qw = __builtin_amdgcn_readfirstlane(qw_next);
       qw_next = p.qwords[blk + 1];
       uint32_t nrows, binfo = 0;
@@ -440,6 +506,19 @@ __global__ void __launch_bounds__(W * 64, W == 16 ? 4 : W == 8 ? 2 : 3) sw_score
       if (lane == 0) __hip_atomic_store(prog_out + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+#ifdef SW_SCORE_TIMELINE
+  if (lane == 0 && blockIdx.x < 256 && wave < 16) {
+    uint32_t* o = g_score_tl + ((size_t)blockIdx.x * 16 + wave) * 8;
+    o[0] = tl_now() - tl_begin;
+    o[1] = tl.queue;
+    o[2] = tl.setup;
+    o[3] = tl.ready;
+    o[4] = tl.done;
+    o[5] = tl.glb;
+    o[6] = tl.strips;
+    o[7] = tl.tail;
+  }
+#endif
 }
 
 }  // namespace
@@ -469,20 +548,21 @@ void score_loop_counts(uint32_t* packed_per_row, uint32_t* aux_per_2rows) {
   *aux_per_2rows = SW_SCORE_ASM_AUX_PER_2ROWS;
 }
 
-// Rows per hand-over block of a pass: the small block where the pass is a few chains of strips and carries one query
-// -- 4-wave workgroups are chosen for exactly those databases (score_waves_per_group), and a database of at most 128
-// groups is fewer chains than the GPU has CUs however long they are (the capacity benchmark's one pair of 4 102 x
-// 4.2e6: 3 groups of ~1 500 strips, 1 210 -> 1 405 GCUPS; a package of 10 queries x 100 targets of 10-200 kb, ~60
-// groups: 33.6 -> 27.0 ms; the reference's default package, 121 groups: 100-102 -> 97-101 ms).
+// Rows per hand-over block of a pass: the small block (ring of twice as many blocks) for every pass of one query; a
+// stacked batch of queries keeps the large one (its block table is built for it), and so does the allocation-free
+// entry point.  History: the small block came in for passes that are a few chains of strips (the capacity
+// benchmark's one pair of 4 102 x 4.2e6, 3 groups of ~1 500 strips: 1 210 -> 1 405 GCUPS; a package of 10 queries x
+// 100 targets of 10-200 kb, ~60 groups: 33.6 -> 27.0 ms) and cost the throughput shapes 4-5 % until the waves began
+// to set their issue priority by their lead (sw_score_kernel); since then it is the faster one everywhere.
 // SW_HIP_SCORE_BLOCK=12 keeps the large block everywhere (experiments).
 int score_block_rows(int waves, bool multi, uint32_t n_groups) {
   static const bool large_only = [] {
     const char* e = getenv("SW_HIP_SCORE_BLOCK");
     return e && atoi(e) == kScoreB;
   }();
-  static const uint32_t few_groups = getenv("SW_HIP_SCORE_FEW_GROUPS") ? (uint32_t)atoi(getenv("SW_HIP_SCORE_FEW_GROUPS")) : 128;  // (experiments)
+  (void)n_groups;
   // (the small block is instantiated for 4 and 16 waves: 8 is an experiment's choice, SW_HIP_SCORE_WAVES, never the library's)
-  return (!multi && !large_only && (waves == 4 || (waves == 16 && n_groups <= few_groups))) ? kScoreBSmall : kScoreB;
+  return (!multi && !large_only && (waves == 4 || waves == 16)) ? kScoreBSmall : kScoreB;
 }
 
 hipError_t launch_score(const ScoreParams& p, int n_workgroups, int waves, int block_rows, hipStream_t stream) {
@@ -511,3 +591,10 @@ hipError_t launch_score(const ScoreParams& p, int n_workgroups, int waves, int b
 }
 
 }  // namespace swhip
+
+#ifdef SW_SCORE_TIMELINE
+extern "C" int sw_hip_debug_score_timeline(uint32_t* out, size_t n_words) {
+  if (n_words > sizeof(swhip::g_score_tl) / 4) n_words = sizeof(swhip::g_score_tl) / 4;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(swhip::g_score_tl), n_words * 4);
+}
+#endif
