@@ -410,7 +410,17 @@ __global__ void __launch_bounds__(W * 64, W == 16 ? 4 : W == 8 ? 2 : 3) sw_score
       if constexpr (W == 16) {
         if (lds_out) {
           const int lead = (int)(cb - (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_flag_load(&done[wave + 1])));
+#if !defined(SW_SCORE_PRIO_MAP) || SW_SCORE_PRIO_MAP == 0
           set_prio(3 - (lead > 0 ? (lead * 3 + DD - 1) / DD : 0));
+#elif SW_SCORE_PRIO_MAP == 1  // (experiments) steeper
+          set_prio(3 - (lead > 0 ? lead : 0));
+#elif SW_SCORE_PRIO_MAP == 2  // flatter at the top
+          set_prio(lead <= 1 ? 3 : lead <= 3 ? 2 : lead <= 4 ? 1 : 0);
+#elif SW_SCORE_PRIO_MAP == 3  // a strip nobody waits for is not urgent
+          set_prio(last ? 1 : 3 - (lead > 0 ? (lead * 3 + DD - 1) / DD : 0));
+#elif SW_SCORE_PRIO_MAP == 4  // two levels
+          set_prio(lead <= 2 ? 3 : 0);
+#endif
         } else {
           set_prio(3);
         }
