@@ -7,7 +7,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import dlsa_amd
 from dlsa_amd import bridge
-qlen, n, tlen = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+qlen, n, tlen = int(args[0]), int(args[1]), int(args[2])
 rng = np.random.default_rng(7)
 lut = np.frombuffer(b"ATCG", dtype=np.uint8)
 q = lut[rng.integers(0, 4, size=qlen, dtype=np.uint8)].tobytes()
@@ -42,3 +43,13 @@ for w in range(16):
     mm = m[:, w]
     if mm.any():
         print(f"  {w:2d} {queue[:, w][mm].mean():8.1f} {setup[:, w][mm].mean():8.1f} {ready[:, w][mm].mean():8.1f} {done[:, w][mm].mean():8.1f} {glb[:, w][mm].mean():8.1f}")
+# distribution over workgroups: when each finished, and the ticket waits of a middle wave
+if "--wg" in sys.argv:
+    ends = tot.max(axis=1)
+    print("workgroup end (us): min %.0f p10 %.0f median %.0f p90 %.0f max %.0f" % (ends[ends > 0].min(), np.percentile(ends[ends > 0], 10), np.median(ends[ends > 0]), np.percentile(ends[ends > 0], 90), ends.max()))
+    q8 = queue[:, 8]
+    print("ticket wait of wave 8 per workgroup (us): min %.0f p10 %.0f median %.0f p90 %.0f max %.0f" % (q8.min(), np.percentile(q8, 10), np.median(q8), np.percentile(q8, 90), q8.max()))
+    st8 = strips[:, 8]; st0 = strips[:, 0]; st15 = strips[:, 15]
+    print("strips of wave 0 / 8 / 15 per workgroup: %s / %s / %s" % (np.bincount(st0.astype(int)).tolist(), np.bincount(st8.astype(int)).tolist(), np.bincount(st15.astype(int)).tolist()))
+    lastu = tail.max(axis=1)
+    print("start of a workgroup's last unit (us): min %.0f median %.0f max %.0f" % (lastu.min(), np.median(lastu), lastu.max()))
