@@ -199,6 +199,9 @@ __device__ __forceinline__ uint32_t lds_addr(const uint32_t* p) {
 }
 __device__ __forceinline__ int pk2(short lo, short hi) { return (int)(((uint32_t)(uint16_t)hi << 16) | (uint16_t)lo); }
 
+#ifndef SW_SCORE_PRIO_W4
+#define SW_SCORE_PRIO_W4 0  // (experiments: the issue priorities in 4-wave workgroups too)
+#endif
 __device__ __forceinline__ void set_prio(int p) {  // wave-uniform
   if (p >= 3) __builtin_amdgcn_s_setprio(3);
   else if (p == 2) __builtin_amdgcn_s_setprio(2);
@@ -407,7 +410,7 @@ __global__ void __launch_bounds__(W * 64, W == 16 ? 4 : W == 8 ? 2 : 3) sw_score
       // scratch/score_timeline.sh, 150-nt reads: waiting for ring room 39 % of all wave time -> 14 %, for the left
       // neighbour 5 % -> 21 %, kernel 17.8 -> 16.5 ms; bench shape 68.7 -> 67.1 ms.  A static priority rising with
       // the wave index loses 2 %, variants that also weigh the input side gain nothing.)
-      if constexpr (W == 16) {
+      if constexpr (W == 16 || SW_SCORE_PRIO_W4) {
         if (lds_out) {
           const int lead = (int)(cb - (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_flag_load(&done[wave + 1])));
 #if !defined(SW_SCORE_PRIO_MAP) || SW_SCORE_PRIO_MAP == 0

@@ -1,14 +1,13 @@
 #!/bin/bash
-# GPU box: variants of the priority map / back-off of the score kernel (scratch/score_variant.sh)
+# GPU box: issue priorities in the 4-wave workgroups of small passes too?  (three alternating rounds: the spread over runs is large)
 cd "$(dirname "$0")/.."
-run() {
-  timeout -k 10 300 python3 scratch/sweep.py c5 c1big c3 | grep -o 'score_kernel_ms": [0-9.]*' | tr '\n' ' ' || exit 1
-  timeout -k 10 200 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline | grep -o '"kernel_ms": [0-9.]*' || exit 1
-}
-for v in "" m1 m2 m3 m4 s8 ""; do
+for r in 1 2 3; do
+for v in "" w4p; do
   if [ -n "$v" ]; then export SW_HIP_LIB=$PWD/gpurun_variants/libsw_$v.so; else unset SW_HIP_LIB; fi
-  echo "-- '$v'"; run
+  echo "-- '$v'"
+  timeout -k 10 100 python3 scratch/lanes15.py 1 | tail -3 | tr '\n' ' '; echo
+  timeout -k 10 100 python3 scratch/lanes15.py 15 | tail -3 | tr '\n' ' '; echo
+  timeout -k 10 100 python3 scratch/bench_rust.py | grep -o "= [0-9.]* GCUPS" | tr '\n' ' '; echo
+  timeout -k 10 100 python3 scratch/sweep.py c1 | grep -o '"search_ms": [0-9.]*'
 done
-export SW_HIP_LIB=$PWD/gpurun_variants/libsw_tl.so
-timeout -k 10 200 python3 scratch/score_timeline.py 150 10000000 150 > gpurun_out/score_tl_reads.txt 2>&1 || exit 1
-timeout -k 10 200 python3 scratch/score_timeline.py 10000 100000 1000 > gpurun_out/score_tl_c2.txt 2>&1 || exit 1
+done
