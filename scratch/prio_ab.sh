@@ -1,13 +1,11 @@
 #!/bin/bash
-# GPU box: issue priorities in the 4-wave workgroups of small passes too?  (three alternating rounds: the spread over runs is large)
+# GPU box: two 8-wave workgroups per CU (ring of 5 blocks of 6 rows) against one 16-wave workgroup
 cd "$(dirname "$0")/.."
-for r in 1 2 3; do
-for v in "" w4p; do
-  if [ -n "$v" ]; then export SW_HIP_LIB=$PWD/gpurun_variants/libsw_$v.so; else unset SW_HIP_LIB; fi
-  echo "-- '$v'"
-  timeout -k 10 100 python3 scratch/lanes15.py 1 | tail -3 | tr '\n' ' '; echo
-  timeout -k 10 100 python3 scratch/lanes15.py 15 | tail -3 | tr '\n' ' '; echo
-  timeout -k 10 100 python3 scratch/bench_rust.py | grep -o "= [0-9.]* GCUPS" | tr '\n' ' '; echo
-  timeout -k 10 100 python3 scratch/sweep.py c1 | grep -o '"search_ms": [0-9.]*'
-done
-done
+run() {
+  timeout -k 10 300 python3 scratch/sweep.py c5 c1big c3 | grep -o 'score_kernel_ms": [0-9.]*\|"top": [0-9]*' | tr '\n' ' '; echo
+  timeout -k 10 200 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline | grep -o '"kernel_ms": [0-9.]*' || exit 1
+}
+echo "-- product"; run
+export SW_HIP_LIB=$PWD/gpurun_variants/libsw_w8.so
+echo "-- w8 build, 16 waves"; run
+echo "-- w8 build, 2 x 8 waves"; SW_HIP_SCORE_WAVES=8 run
