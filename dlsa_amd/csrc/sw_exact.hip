@@ -18,7 +18,7 @@
 // cell's v_max3 (see "arithmetic of one cell").  The walker knows H along the path (it subtracts what each step
 // added), so no "zero" code is needed: 0 appears only where H = 0, and the walk stops there.
 // Layout: word[((strip * nkb + k/16) * RPL + r) * 64 + lane], step k of that lane in bits
-// [2*(15 - k%16), +2); lane's row i = strip*256 + lane*RPL + r, its column at step k is j = k - lane + 1.
+// [2*(k%16), +2); lane's row i = strip*256 + lane*RPL + r, its column at step k is j = k - lane + 1.
 #include "sw_internal.h"
 
 // back-off of the boundary poll (units of 64 clocks)
@@ -182,7 +182,9 @@ __device__ __forceinline__ void exact_steps16(const uint32_t (&qs)[RPL], const b
           hb = hn;
         }
       }
-      if (DIRS) acc[r] = (acc[r] << 2) | ((uint32_t)ht & 3u);  // (a masked cell's code is never read)
+      // one v_alignbit: the word moves down two bits and the cell's code enters at the top, so after the 16 steps of
+      // a block step k sits in bits [2 * (k % 16), +2)  (a masked cell's code is never read)
+      if (DIRS) acc[r] = __builtin_amdgcn_alignbit((uint32_t)ht, acc[r], 2);
       if (hb > bestv[r]) bestj[r] = (uint32_t)jv;  // strict: the first (smallest j) maximal cell of the row
       bestv[r] = max(bestv[r], hb);
       h[r] = hn;
@@ -526,7 +528,7 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
           uint32_t code = 0, qsym = 0x30000u, tsym = 0x40000u;
           if (valid) {
             const uint32_t w = wdir[(((uint32_t)kt >> 4) - wbase) * SH + (uint32_t)wr];
-            code = (w >> ((~(uint32_t)kt & 15u) * 2)) & 3u;
+            code = (w >> (((uint32_t)kt & 15u) * 2)) & 3u;
             qsym = wq[wr];
             tsym = wt[jt - tbase];
           }
@@ -624,7 +626,7 @@ __global__ void __launch_bounds__(64) sw_walk_kernel(const ExactPair* pairs, Exa
         bool eq = false;
         if (valid) {
           const uint32_t w = wdir[(((uint32_t)kt >> 4) - wbase) * SH + (uint32_t)wr];
-          code = (w >> ((~(uint32_t)kt & 15u) * 2)) & 3u;
+          code = (w >> (((uint32_t)kt & 15u) * 2)) & 3u;
           eq = wq[wr] == wt[jt - tbase];
         }
         const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
