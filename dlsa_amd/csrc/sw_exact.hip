@@ -141,7 +141,7 @@ __device__ __forceinline__ int sat_sub(int a, uint32_t b) {  // max(a - b, 0) fo
 template <int RPL, bool DIRS, bool MASK, bool WIN>
 __device__ __forceinline__ void exact_steps16(const uint32_t (&qs)[RPL], const bool (&valid)[RPL], int (&h)[RPL],
                                               int (&bestv)[RPL], uint32_t (&bestj)[RPL], uint32_t (&acc)[RPL],
-                                              int& top_prev, int& last_out, int& tcur, int (&hist)[16], int& jv,
+                                              int& top_prev, int& last_out, int& tcur, int& pub, int& jv,
                                               int bcur, int tblk, const CellConsts& C, uint32_t lim0,
                                               uint32_t Tlim, const int (&leftv)[RPL]) {
 #pragma unroll
@@ -192,8 +192,12 @@ __device__ __forceinline__ void exact_steps16(const uint32_t (&qs)[RPL], const b
     }
     top_prev = top;
     last_out = h[RPL - 1];
-    // bottom row of the strip leaves through lane 63: column k - 62 at step k; already tagged for the hand-over
-    hist[k4] = (int)((uint32_t)last_out | kTag);
+    // The bottom row of the strip leaves through lane 63: column k - 62 at step k.  `pub` is a shift register ACROSS
+    // the lanes: every step it moves one lane down (lane i takes lane i + 1's word) and lane 63, which has no source,
+    // keeps its own new last_out -- after the 16 steps of a block lanes 48..63 hold the block's 16 values in column
+    // order, and ONE store instruction of 64 contiguous bytes publishes them (four 16-byte stores from lane 63 cost a
+    // chained strip 15 ns per step: it is the number of store instructions that counts, profiles/r03_exact_step.txt).
+    pub = __builtin_amdgcn_update_dpp(last_out, pub, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
     jv++;
   }
 }
@@ -209,8 +213,11 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
   constexpr uint32_t SH = 64 * RPL;
   const uint32_t nstrips = exact_nstrips(Q, RPL);
 
-  const gptr<const int32_t> bin = glb((const int32_t*)P.bnd) + (size_t)(strip > 0 ? strip - 1 : 0) * P.bnd_pitch;  // bottom row of strip-1
-  const gptr<int32_t> bout = glb(P.bnd) + (size_t)strip * P.bnd_pitch;
+  // (column c of a row sits at word c + kBndShift: the 16 columns 16 g - 62 .. 16 g - 47 a block publishes then start on
+  // a 64-byte line -- rows are whole lines, sw_lib.cpp -- and the one store that carries them is one line)
+  constexpr int kBndShift = 14;
+  const gptr<const int32_t> bin = glb((const int32_t*)P.bnd) + (size_t)(strip > 0 ? strip - 1 : 0) * P.bnd_pitch + kBndShift;  // bottom row of strip-1
+  const gptr<int32_t> bout = glb(P.bnd) + (size_t)strip * P.bnd_pitch + kBndShift;
   const auto gq = glb(P.q);
   const auto gt = glb(P.t);
   const auto gleft = glb(P.left);
@@ -240,7 +247,7 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
   // wavefront: every lane above them is forced to the boundary column when it passes column 0.)
   int top_prev = (WIN && lane == 0 && ibase > 0) ? 4 * (int)((gleft[(size_t)(ibase - 1) * 64] >> P.left_shift) & 0xffffu) : 0;
   int last_out = h[RPL - 1];  // lane 1's first diagonal is lane 0's last row at column 0: the boundary again
-  int hist[16];
+  int pub = 0;
   int tcur = 0x20000;
   int jv = 1 - lane;  // the column this lane works on
 
@@ -285,34 +292,22 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
     // (a window with a boundary column runs masked while any lane is still at or left of column 0: lane 63
     // reaches column 1 at step 63)
     if (plain && g * 16 + 16 <= mincol && !(WIN && g < 4))
-      exact_steps16<RPL, DIRS, false, WIN>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
+      exact_steps16<RPL, DIRS, false, WIN>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, pub, jv, bcur, tblk,
                                  C, lim0, P.Tlim, leftv);
     else
-      exact_steps16<RPL, DIRS, true, WIN>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, hist, jv, bcur, tblk,
+      exact_steps16<RPL, DIRS, true, WIN>(qs, valid, h, bestv, bestj, acc, top_prev, last_out, tcur, pub, jv, bcur, tblk,
                                 C, lim0, P.Tlim, leftv);
     if (DIRS) {
       const gptr<uint32_t> w = glb(P.dirs) + ((size_t)(strip * P.nkb + g) * RPL) * 64 + lane;
 #pragma unroll
       for (int r = 0; r < RPL; r++) w[r * 64] = acc[r];
     }
-    if (publish && lane == 63) {
-      // lane 63 finished columns 16 g - 62 .. 16 g - 47 of the strip's bottom row during this block: four 16-byte
-      // device-scope stores (a wave may only have 63 memory operations in flight; sixteen dword stores per block
-      // on top of the direction words made the producer wait for its own stores)
-      const int col0 = (int)(g * 16) - 62;
-      if (col0 >= 1 && (uint32_t)(col0 + 15) <= maxcol) {
-        typedef int i4v __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int i = 0; i < 16; i += 4) {
-          const i4v v = {hist[i], hist[i + 1], hist[i + 2], hist[i + 3]};
-          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(bout + col0 + i), "v"(v) : "memory");
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 16; i++)
-          if (col0 + i >= 1 && (uint32_t)(col0 + i) <= maxcol)
-            __hip_atomic_store(bout + col0 + i, hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+    if (publish && lane >= 48) {
+      // lane 63 finished columns 16 g - 62 .. 16 g - 47 of the strip's bottom row during this block; lane 48 + i holds
+      // column 16 g - 62 + i (see exact_steps16).  One device-scope store, each word with its "published" tag.
+      const int col = (int)(g * 16) - 62 + (lane - 48);
+      if (col >= 1 && (uint32_t)col <= maxcol)
+        __hip_atomic_store(bout + col, (int)((uint32_t)pub | kTag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 #pragma unroll

@@ -430,7 +430,9 @@ int exact_chunk_begin(Context& c, Workspace& ws, const PairSpec* specs, size_t b
       e.phaseQp = pp.phaseQp;
       e.straight = pp.straight;
       const uint32_t maxcol = std::max(pp.Tlim, pp.T0);
-      e.bnd_pitch = maxcol + 2;
+      // (rows of whole 64-byte lines: a strip publishes 16 columns per block with ONE 64-byte store, which the kernel's
+      // 14-word offset into the row puts on a line boundary -- sw_exact.hip, kBndShift)
+      e.bnd_pitch = (maxcol + 2 + 14 + 15) & ~15u;
       e.nkb = exact_nsteps(maxcol, s.Q, rpl) / 16;
       e.n_units = std::max<uint32_t>(exact_nstrips(s.Q, rpl), 1);
       if (want_trace) dirw[i] = exact_dir_words(s.Q, maxcol, rpl);
@@ -493,7 +495,7 @@ int exact_chunk_begin(Context& c, Workspace& ws, const PairSpec* specs, size_t b
                in_sym = in_order + align16(n_units * 4);
   const size_t in_bytes = in_sym + align16(pool_syms * 2 + 16);
   const size_t ctl_words = 64 + n;
-  const size_t z_bnd = align16(ctl_words * 4), z_bytes = z_bnd + align16(std::max<size_t>(bnd_ints * 4, 16));
+  const size_t z_bnd = (ctl_words * 4 + 63) & ~(size_t)63, z_bytes = z_bnd + align16(std::max<size_t>(bnd_ints * 4, 16));
   const size_t out_ops = align16(n * sizeof(ExactOut)), out_bytes = out_ops + (want_trace ? align16(ops_bytes) : 0);
   int rc;
   if ((rc = ws.xin.ensure(in_bytes))) return rc;
@@ -660,7 +662,7 @@ int run_exact_chunk(Context& c, Workspace& ws, const PairSpec* specs, size_t beg
 // bytes of device scratch one pair needs (the split of a submission into chunks goes by it)
 size_t exact_pair_bytes(const PairSpec& sp, int rpl, bool want_trace) {
   const PathParams pp = resolve_path(sp.path, sp.Q, sp.T);
-  size_t b = (size_t)sp.Q * 2 + (size_t)sp.T * 2 + (size_t)std::max<uint32_t>(exact_nstrips(sp.Q, rpl), 1) * (sp.T + 2) * 4 + 256;
+  size_t b = (size_t)sp.Q * 2 + (size_t)sp.T * 2 + (size_t)std::max<uint32_t>(exact_nstrips(sp.Q, rpl), 1) * (sp.T + 32) * 4 + 256;
   if (want_trace) b += exact_dir_words(sp.Q, std::max(pp.Tlim, pp.T0), rpl) * 4 + sp.Q + sp.T;
   return b;
 }
