@@ -3,12 +3,12 @@
 set -e
 OUT=gpurun_out/r03_fuzz_exact.txt
 : > $OUT
-echo "tree: $(cat .git_head 2>/dev/null || echo unknown) (exact kernel: direction codes through v_alignbit)" >> $OUT
-for seed in 701 702; do
+echo "tree: $(cat .git_head 2>/dev/null || echo unknown) (exact kernel: one line-aligned publication store per block)" >> $OUT
+for seed in 801 802; do
   timeout -k 10 280 python3 scratch/fuzz.py $seed 30000 >> $OUT 2>&1
 done
-timeout -k 10 170 python3 scratch/fuzz_long.py 721 600 >> $OUT 2>&1
-timeout -k 10 170 python3 scratch/fuzz_package.py 731 40 >> $OUT 2>&1
-timeout -k 10 170 python3 scratch/fuzz_package.py 751 60 sets >> $OUT 2>&1
-timeout -k 10 170 python3 scratch/fuzz_db.py 741 100 >> $OUT 2>&1
+timeout -k 10 170 python3 scratch/fuzz_long.py 821 600 >> $OUT 2>&1
+timeout -k 10 170 python3 scratch/fuzz_package.py 831 40 >> $OUT 2>&1
+timeout -k 10 170 python3 scratch/fuzz_package.py 851 60 sets >> $OUT 2>&1
+timeout -k 10 170 python3 scratch/fuzz_db.py 841 100 >> $OUT 2>&1
 echo "all fuzzers done" >> $OUT
