@@ -1389,8 +1389,8 @@ int exact_one_fixed(Context& c, HostArena& arena, const uint16_t* qsym, uint32_t
   const size_t in_units = align16(sizeof(ExactPair)), in_order = in_units + align16((size_t)n_units * 4),
                in_q = in_order + align16((size_t)n_units * 4), in_t = in_q + align16((size_t)Q * 2 + 2),
                in_bytes = in_t + align16((size_t)T * 2 + 16);
-  const size_t ctl_words = 64 + 1, z_bnd = align16(ctl_words * 4),
-               z_bytes = z_bnd + align16(std::max<size_t>((size_t)n_units * (maxcol + 2) * 4, 16));
+  const size_t ctl_words = 64 + 1, z_bnd = (ctl_words * 4 + 63) & ~(size_t)63,
+               z_bytes = z_bnd + align16(std::max<size_t>((size_t)n_units * exact_bnd_pitch(maxcol) * 4, 16));
   int rc;
   if ((rc = ws.xin.ensure(in_bytes))) return rc;
   if ((rc = ws.xzero.ensure(z_bytes))) return rc;
@@ -1412,7 +1412,7 @@ int exact_one_fixed(Context& c, HostArena& arena, const uint16_t* qsym, uint32_t
   e.phaseQp = pp.phaseQp;
   e.straight = pp.straight;
   e.bnd = (int32_t*)(d_zero + z_bnd);
-  e.bnd_pitch = maxcol + 2;
+  e.bnd_pitch = exact_bnd_pitch(maxcol);
   e.dirs = nullptr;
   e.nkb = exact_nsteps(maxcol, Q, rpl) / 16;
   e.ops = nullptr;

@@ -214,8 +214,8 @@ __device__ __forceinline__ void exact_strip(const ExactPair& P, const ExactWork&
   const uint32_t nstrips = exact_nstrips(Q, RPL);
 
   // (column c of a row sits at word c + kBndShift: the 16 columns 16 g - 62 .. 16 g - 47 a block publishes then start on
-  // a 64-byte line -- rows are whole lines, sw_lib.cpp -- and the one store that carries them is one line)
-  constexpr int kBndShift = 14;
+  // a 64-byte line -- rows are whole lines, exact_bnd_pitch -- and the one store that carries them is one line)
+  constexpr int kBndShift = (int)kExactBndShift;
   const gptr<const int32_t> bin = glb((const int32_t*)P.bnd) + (size_t)(strip > 0 ? strip - 1 : 0) * P.bnd_pitch + kBndShift;  // bottom row of strip-1
   const gptr<int32_t> bout = glb(P.bnd) + (size_t)strip * P.bnd_pitch + kBndShift;
   const auto gq = glb(P.q);

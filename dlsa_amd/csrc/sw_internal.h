@@ -103,6 +103,11 @@ __host__ __device__ inline uint32_t exact_nsteps(uint32_t maxcol, uint32_t Q, in
   const uint32_t lanes = Q > 64u * (uint32_t)rpl ? 64u : (Q + (uint32_t)rpl - 1) / (uint32_t)rpl;
   return ((maxcol + (lanes ? lanes : 1u) - 1 + 15) / 16) * 16;
 }
+// Words per boundary row (ExactPair::bnd_pitch): whole 64-byte lines, with room for the kernel's 14-word shift of the
+// columns (sw_exact.hip, kBndShift: the 16 columns a block publishes then start on a line).  Every builder of an
+// ExactPair sizes and strides its rows with this; the region itself must start on a 64-byte boundary.
+constexpr uint32_t kExactBndShift = 14;
+inline uint32_t exact_bnd_pitch(uint32_t maxcol) { return (maxcol + 2 + kExactBndShift + 15) & ~15u; }
 inline size_t exact_dir_words(uint32_t Q, uint32_t maxcol, int rpl) {
   return (size_t)exact_nstrips(Q, rpl) * (exact_nsteps(maxcol, Q, rpl) / 16) * rpl * 64;
 }

@@ -430,9 +430,7 @@ int exact_chunk_begin(Context& c, Workspace& ws, const PairSpec* specs, size_t b
       e.phaseQp = pp.phaseQp;
       e.straight = pp.straight;
       const uint32_t maxcol = std::max(pp.Tlim, pp.T0);
-      // (rows of whole 64-byte lines: a strip publishes 16 columns per block with ONE 64-byte store, which the kernel's
-      // 14-word offset into the row puts on a line boundary -- sw_exact.hip, kBndShift)
-      e.bnd_pitch = (maxcol + 2 + 14 + 15) & ~15u;
+      e.bnd_pitch = exact_bnd_pitch(maxcol);  // (rows of whole 64-byte lines, sw_internal.h)
       e.nkb = exact_nsteps(maxcol, s.Q, rpl) / 16;
       e.n_units = std::max<uint32_t>(exact_nstrips(s.Q, rpl), 1);
       if (want_trace) dirw[i] = exact_dir_words(s.Q, maxcol, rpl);
@@ -662,7 +660,7 @@ int run_exact_chunk(Context& c, Workspace& ws, const PairSpec* specs, size_t beg
 // bytes of device scratch one pair needs (the split of a submission into chunks goes by it)
 size_t exact_pair_bytes(const PairSpec& sp, int rpl, bool want_trace) {
   const PathParams pp = resolve_path(sp.path, sp.Q, sp.T);
-  size_t b = (size_t)sp.Q * 2 + (size_t)sp.T * 2 + (size_t)std::max<uint32_t>(exact_nstrips(sp.Q, rpl), 1) * (sp.T + 32) * 4 + 256;
+  size_t b = (size_t)sp.Q * 2 + (size_t)sp.T * 2 + (size_t)std::max<uint32_t>(exact_nstrips(sp.Q, rpl), 1) * exact_bnd_pitch(sp.T + 1) * 4 + 256;
   if (want_trace) b += exact_dir_words(sp.Q, std::max(pp.Tlim, pp.T0), rpl) * 4 + sp.Q + sp.T;
   return b;
 }
